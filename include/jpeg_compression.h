@@ -1,0 +1,249 @@
+/*
+ * jpeg_compression.h -- C-ABI of the MI355X-native BMP -> grayscale baseline-JPEG encoder.
+ *
+ * This is the drop-in boundary for the reference's encode path
+ * (strbac-damjan/jpeg-image-compression).  Every entry point cites the reference interface
+ * it replaces; file:line are relative to the reference root.  Plain C types only: a
+ * maintainer binds these from C (natural_c/src/main.c links unchanged), from ctypes, or
+ * from any FFI.  See INTEGRATION.md for the reference-side stubs.
+ *
+ * Three levels, lowest first:
+ *   1. jpegamd_*            device-resident, stream-ordered hot path (what bench.py times)
+ *   2. JpegCompression_Init / convertToJpeg(JPEG_COMPRESSION_DTO*)
+ *                           the reference's accelerator boundary
+ *                           (dsp_port/jpeg_compression/include/jpeg_compression.h:32-77,111)
+ *   3. loadBMPImage / saveJPEGGrayscale / stage functions
+ *                           the natural_c library surface
+ *                           (natural_c/include/bmp_handler.h:37-47, jpeg_handler.h:100-109)
+ *
+ * There is NO CPU fallback anywhere behind this header: without a HIP device every
+ * compute entry point fails with JPEGAMD_ERR_NO_DEVICE (and the natural_c-shaped ones
+ * return NULL / false after printing the reason).
+ *
+ * Threading: one in-flight call per encoder context; JpegCompression_Init once per
+ * process (the reference is single-threaded and non-re-entrant as well:
+ * natural_c/src/core/huffman.c:9-11,106-117).
+ */
+#ifndef JPEGAMD_JPEG_COMPRESSION_H
+#define JPEGAMD_JPEG_COMPRESSION_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * Status codes.  0 / -6 / -8 keep the reference's meaning
+ * (dsp_port/jpeg_compression/src/jpeg_compression.c:181,206,214).
+ * ---------------------------------------------------------------------------------- */
+#define JPEGAMD_OK                0
+#define JPEGAMD_ERR_ARG          (-1)  /* NULL / non-positive dims / bad stride */
+#define JPEGAMD_ERR_NO_DEVICE    (-2)  /* no HIP device or kernel image not loadable */
+#define JPEGAMD_ERR_HIP          (-3)  /* a HIP runtime call failed */
+#define JPEGAMD_ERR_NOT_INIT     (-4)  /* JpegCompression_Init() not called */
+#define JPEGAMD_ERR_TOO_LARGE    (-5)  /* image exceeds the context's max dims */
+#define JPEGAMD_ERR_RLE_CAPACITY (-6)  /* reference: RLE capacity exhausted */
+#define JPEGAMD_ERR_BMP          (-7)  /* malformed BMP (magic / bit count / compression / short) */
+#define JPEGAMD_ERR_HUFF_CAPACITY (-8) /* reference: Huffman buffer too small */
+
+#define JPEGAMD_JFIF_PREFIX_BYTES 328  /* APP0+DQT+SOF0+DHT+DHT+SOS, natural_c/src/io/jpeg_handler.c:220-233 */
+
+/* ------------------------------------------------------------------------------------
+ * Level 1: device-resident hot path
+ * ---------------------------------------------------------------------------------- */
+
+/* Pixel source description.  Covers both things the reference feeds its codec:
+ *  - BMP file rows as they lie in the file: BGR, bottom-up, stride (3W+3)&~3
+ *    (natural_c/src/io/bmp_handler.c:68-75,109-122)      -> JPEGAMD_ORDER_BGR, bottom_up=1
+ *  - a loaded BMPImage: RGB, top-down, tightly packed
+ *    (natural_c/include/bmp_handler.h:37-41)              -> JPEGAMD_ORDER_RGB, bottom_up=0
+ */
+#define JPEGAMD_ORDER_BGR 0
+#define JPEGAMD_ORDER_RGB 1
+
+typedef struct JpegAmdImage {
+    const void *pixels;    /* DEVICE pointer to the first stored row */
+    int32_t width;         /* original (unpadded) width,  1..65535 */
+    int32_t height;        /* original (unpadded) height, 1..65535 */
+    int32_t row_stride;    /* bytes between stored rows (>= 3*width) */
+    int32_t bottom_up;     /* 1: stored row 0 is the LAST image row (BMP default) */
+    int32_t channel_order; /* JPEGAMD_ORDER_BGR or JPEGAMD_ORDER_RGB */
+    int32_t quality;       /* 0 or 50: the reference's only table
+                              (natural_c/src/core/jpeg_tables.c:3-12); 1..100 otherwise =
+                              libjpeg scaling of that table (extension) */
+} JpegAmdImage;
+
+/* Per-call statistics, filled on request (host memory).  The *_ns fields are hipEvent
+ * times of the device phases; they play the role of the reference DTO's cycles_* fields
+ * (dsp_port/jpeg_compression/include/jpeg_compression.h:55-62). */
+typedef struct JpegAmdStats {
+    uint64_t jfif_bytes;        /* total bytes written (prefix + segment + EOI) */
+    uint64_t entropy_bits;      /* unstuffed entropy-coded bits */
+    uint64_t stuffed_bytes;     /* number of 0x00 bytes inserted after 0xFF */
+    uint64_t exact_fallbacks;   /* coefficients recomputed in the reference's float order */
+    uint64_t ns_transform;      /* fused luma+DCT+quant+zigzag+RLE/Huffman-symbol kernel */
+    uint64_t ns_scan;           /* bit-offset / stuffing prefix sums */
+    uint64_t ns_pack;           /* bitstream stitch + 0xFF stuffing + container */
+    uint64_t ns_total;
+} JpegAmdStats;
+
+typedef struct JpegAmdEncoder JpegAmdEncoder;   /* opaque; owns device scratch */
+
+/* Create a context able to encode images up to max_width x max_height on the current
+ * HIP device.  Scratch is allocated once here (nothing is allocated per call). */
+int32_t jpegamd_encoder_create(JpegAmdEncoder **enc, int32_t max_width, int32_t max_height);
+int32_t jpegamd_encoder_destroy(JpegAmdEncoder *enc);
+
+/* Upper bound on the JFIF bytes an image of this size can produce (every block at the
+ * 1658-bit worst case and every byte stuffed): size `out` with this. */
+uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height);
+
+/* Enqueue one encode on `stream` (a hipStream_t, or NULL for the default stream).
+ *   out_dev        DEVICE buffer receiving the JFIF file bytes
+ *   out_capacity   its size in bytes (>= jpegamd_max_jfif_bytes for a guaranteed fit;
+ *                  smaller is allowed, overflow is reported through out_size_dev = 0 and
+ *                  JPEGAMD_ERR_HUFF_CAPACITY from jpegamd_encoder_finish)
+ *   out_size_dev   DEVICE uint64_t receiving the byte count
+ *   with_container 1: JFIF prefix + entropy segment + EOI (what saveJPEGGrayscale writes,
+ *                  natural_c/src/io/jpeg_handler.c:220-262); 0: entropy segment only
+ *                  (what the reference's accelerator hands back,
+ *                  dsp_port/jpeg_compression/src/jpeg_compression.c:198-203)
+ * Asynchronous: returns once the kernels are enqueued. */
+int32_t jpegamd_encode_async(JpegAmdEncoder *enc, const JpegAmdImage *img, void *out_dev,
+                             uint64_t out_capacity, uint64_t *out_size_dev,
+                             int32_t with_container, void *stream);
+
+/* Block until the last enqueued encode on this context finished; optionally fetch stats
+ * (stats may be NULL).  Returns JPEGAMD_ERR_HUFF_CAPACITY if the output did not fit. */
+int32_t jpegamd_encoder_finish(JpegAmdEncoder *enc, JpegAmdStats *stats);
+
+/* Turn per-phase hipEvent timing on/off (off by default: events cost launches). */
+int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *enc, int32_t enabled);
+
+/* Stage taps for parity tests and the DTO's debug pointers.  Runs the same device code as
+ * the hot path over the whole image and writes, for every 8x8 block in raster block order,
+ * into DEVICE buffers (any of them may be NULL):
+ *   y_centered   int8  [NB][64]  luma - 128, row-major inside the block  (converter.c:51,84-86)
+ *   quant_zigzag int16 [NB][64]  quantised coefficients in zigzag order  (quantization.c:34-36, zigzag.c:51-61)
+ *   exact_mask   u64   [NB]      bit k set = zigzag-raster coefficient k took the exact path
+ * Synchronous. */
+int32_t jpegamd_debug_stages(JpegAmdEncoder *enc, const JpegAmdImage *img, int8_t *y_centered,
+                             int16_t *quant_zigzag, uint64_t *exact_mask);
+
+/* Exact-order DCT of arbitrary centred blocks on the device (dct.c:63-96), for the float
+ * parity test: in int8 [n][64] (row-major), out float [n][64] (out[u*8+v]).  DEVICE ptrs. */
+int32_t jpegamd_debug_dct_exact(JpegAmdEncoder *enc, const int8_t *blocks, float *coeffs, int64_t nblocks);
+
+/* Deterministic integer-only synthetic BMP generator (host code, no device needed); the
+ * same generator feeds tests, goldens and bench.py on every machine.
+ *   kind: 0 photo-like (smooth + textured regions), 1 uniform noise, 2 flat grey (seed&255),
+ *         3 horizontal+vertical gradient
+ *   flags bit0: top-down (negative biHeight); bit1: 138-byte offset to pixel data (V5-style)
+ * Returns the BMP file size, or 0 if cap is too small (call with out=NULL to query). */
+uint64_t jpegamd_synth_bmp(int32_t width, int32_t height, uint32_t seed, int32_t kind,
+                           uint32_t flags, uint8_t *out, uint64_t cap);
+
+const char *jpegamd_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Level 2: the reference's accelerator boundary
+ * ---------------------------------------------------------------------------------- */
+
+/* Same role and field order as dsp_port/jpeg_compression/include/jpeg_compression.h:32-64.
+ * Differences forced by the hardware: the TI planar r / gb "physical" pointers become ONE
+ * interleaved device pointer (r_phy_ptr) plus layout fields appended at the end; the
+ * cycle counters count nanoseconds.  As in the reference the CALLER owns every buffer and
+ * the callee fills rle_count, huff_size and the counters. */
+typedef struct JPEG_COMPRESSION_DTO {
+    int32_t width;
+    int32_t height;
+
+    uint64_t r_phy_ptr;       /* DEVICE address of the interleaved pixel rows */
+    uint64_t gb_phy_ptr;      /* unused (kept for layout compatibility), must be 0 */
+
+    /* First-block debug taps, HOST addresses, each may be 0
+     * (dsp_port/jpeg_compression/src/jpeg_compression.c:150-169). */
+    uint64_t y_phy_ptr;       /* int8  [64] */
+    uint64_t dct_phy_ptr;     /* float [64] exact-order DCT of block 0 */
+    uint64_t quant_phy_ptr;   /* int16 [64] raster order */
+    uint64_t zigzag_phy_ptr;  /* int16 [64] zigzag order */
+
+    uint64_t rle_phy_ptr;     /* unused: symbols never leave the chip; must be 0 */
+    uint32_t rle_count;       /* OUT: number of run/size symbols coded */
+
+    uint64_t huff_phy_ptr;    /* DEVICE address receiving the entropy-coded segment */
+    uint32_t huff_size;       /* IN: capacity in bytes; OUT: bytes written */
+
+    uint64_t cycles_color_conversion; /* OUT, ns: the five per-block stages run fused, so */
+    uint64_t cycles_dct;              /*   cycles_dct carries the fused kernel's time and  */
+    uint64_t cycles_quantization;     /*   the other four fused-stage fields are 0         */
+    uint64_t cycles_zigzag;
+    uint64_t cycles_rle;
+    uint64_t cycles_huffman;          /* OUT, ns: scan + pack kernels */
+    uint64_t cycles_total;            /* OUT, ns */
+
+    /* MI355X additions */
+    int32_t row_stride;
+    int32_t bottom_up;
+    int32_t channel_order;
+    int32_t quality;
+} JPEG_COMPRESSION_DTO;
+
+/* dsp_port/jpeg_compression/include/jpeg_compression.h:77 (registration of the remote
+ * service becomes: pick the HIP device, load kernels, allocate the shared context).
+ * Idempotent; returns 0 on success like the reference. */
+int32_t JpegCompression_Init(void);
+int32_t JpegCompression_DeInit(void);
+/* Optional: pre-size the shared context (Init sizes it for 2048x2048, or JPEGAMD_INIT_DIM;
+ * convertToJpeg / saveJPEGGrayscale grow it on demand). */
+int32_t JpegCompression_Reserve(int32_t max_width, int32_t max_height);
+
+/* dsp_port/jpeg_compression/include/jpeg_compression.h:111.  Synchronous.
+ * Returns 0, or -6 / -8 with the reference's meaning, or a JPEGAMD_ERR_* code. */
+int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto);
+
+/* dsp_port/jpeg_compression/include/jpeg_compression.h:72-73 (handler signature). */
+int32_t JpegCompression_RemoteServiceHandler(char *service_name, uint32_t cmd, void *prm,
+                                             uint32_t prm_size, uint32_t flags);
+
+/* ------------------------------------------------------------------------------------
+ * Level 3: the natural_c library surface (same names and signatures, so
+ * natural_c/src/main.c compiles and links against this library unchanged)
+ * ---------------------------------------------------------------------------------- */
+
+/* natural_c/include/bmp_handler.h:37-41 */
+typedef struct BMPImage {
+    int32_t width;
+    int32_t height;
+    uint8_t *data;   /* RGB, top-down, tightly packed; malloc'd */
+} BMPImage;
+
+/* natural_c/include/bmp_handler.h:43-45 (src/io/bmp_handler.c:5-129). Host code. */
+BMPImage *loadBMPImage(const char *filename);
+void freeBMPImage(BMPImage *image);
+
+/* natural_c/include/jpeg_handler.h:107 (src/io/jpeg_handler.c:119-282): runs the whole
+ * pipeline on the GPU and writes the file.  Opens the file first, prints the reference's
+ * progress lines, returns false on any failure. */
+bool saveJPEGGrayscale(const char *filename, const BMPImage *img);
+
+/* In-memory variants used by tests and the CLI (no reference counterpart; they are what
+ * loadBMPImage + saveJPEGGrayscale do without the file system).
+ * jpegamd_encode_bmp_memory: BMP file bytes (host) -> JFIF file bytes (host).
+ * Returns the JFIF size, or a negative JPEGAMD_ERR_* code. */
+int64_t jpegamd_encode_bmp_memory(const uint8_t *bmp, uint64_t bmp_len, int32_t quality,
+                                  uint8_t *out, uint64_t out_cap);
+
+/* Parse a BMP header the way loadBMPImage does (bmp_handler.c:22-88); fills a JpegAmdImage
+ * whose `pixels` is an OFFSET into the file (cast to pointer), for callers that upload the
+ * file themselves.  Returns 0 or JPEGAMD_ERR_BMP. */
+int32_t jpegamd_parse_bmp(const uint8_t *bmp, uint64_t bmp_len, JpegAmdImage *view,
+                          uint64_t *pixel_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGAMD_JPEG_COMPRESSION_H */

@@ -1,0 +1,407 @@
+// jpegamd_api.cpp -- C-ABI host layer over the HIP kernels (include/jpeg_compression.h).
+//
+// Level 1 (jpegamd_*): device-resident, stream-ordered encode.
+// Level 2 (JpegCompression_Init / convertToJpeg): the reference's accelerator boundary
+//          (dsp_port/jpeg_compression/src/jpeg_compression.c:6-33,35-216).
+// There is no CPU fallback: without a HIP device every compute entry fails.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "jpeg_compression.h"
+#include "jpegamd_internal.h"
+
+using namespace jpegamd;
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            std::fprintf(stderr, "jpegamd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                                   \
+            return JPEGAMD_ERR_HIP;                                                             \
+        }                                                                                       \
+    } while (0)
+
+struct JpegAmdEncoder {
+    int device = -1;
+    int max_w = 0, max_h = 0, max_segs = 0;
+    // device scratch
+    uint32_t *seg_words = nullptr, *seg_bits = nullptr, *seg_syms = nullptr, *seg_exact = nullptr;
+    uint32_t *seg_ff = nullptr, *ovf_words = nullptr, *huff = nullptr, *status = nullptr;
+    uint64_t *seg_bitstart = nullptr, *seg_ffstart = nullptr;
+    uint8_t *prefix = nullptr;
+    ScanStats *stats_dev = nullptr;
+    // host mirrors (pinned)
+    struct HostMirror {
+        ScanStats stats;
+        uint64_t out_size;
+        uint32_t status;
+    } *mirror = nullptr;
+    // cached constants
+    int cur_quality = -1;
+    uint8_t qtable[64];
+    QuantConsts qc;
+    int prefix_w = -1, prefix_h = -1, prefix_q = -1;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // last call
+    hipStream_t last_stream = nullptr;
+    bool pending = false;
+    bool timed = false;
+};
+
+static int segs_for(int w, int h, int *bw, int *bh, int *spr) {
+    const int blocks_w = (w + 7) / 8, blocks_h = (h + 7) / 8;
+    const int per_row = (blocks_w + kSegBlocks - 1) / kSegBlocks;
+    if (bw) *bw = blocks_w;
+    if (bh) *bh = blocks_h;
+    if (spr) *spr = per_row;
+    return blocks_h * per_row;
+}
+
+extern "C" const char *jpegamd_version(void) { return "jpegamd 0.1 (gfx950)"; }
+
+extern "C" uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height) {
+    if (width <= 0 || height <= 0) return 0;
+    const uint64_t nb = (uint64_t)((width + 7) / 8) * (uint64_t)((height + 7) / 8);
+    // every block at the worst-case bit count, every byte stuffed, + container
+    return JPEGAMD_JFIF_PREFIX_BYTES + 2 + 2 * ((nb * kMaxBlockBits + 7) / 8 + 1) + 16;
+}
+
+static void free_scratch(JpegAmdEncoder *e) {
+    hipFree(e->seg_words); hipFree(e->seg_bits); hipFree(e->seg_syms); hipFree(e->seg_exact);
+    hipFree(e->seg_ff); hipFree(e->ovf_words); hipFree(e->seg_bitstart); hipFree(e->seg_ffstart);
+    e->seg_words = e->seg_bits = e->seg_syms = e->seg_exact = e->seg_ff = e->ovf_words = nullptr;
+    e->seg_bitstart = e->seg_ffstart = nullptr;
+}
+
+static int32_t alloc_scratch(JpegAmdEncoder *e, int max_w, int max_h) {
+    const int segs = segs_for(max_w, max_h, nullptr, nullptr, nullptr);
+    HIP_TRY(hipMalloc((void **)&e->seg_words, (size_t)segs * kSegCapWords * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->ovf_words, (size_t)segs * kOvfWords * 64 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->seg_bits, (size_t)segs * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->seg_syms, (size_t)segs * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->seg_exact, (size_t)segs * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->seg_ff, (size_t)segs * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->seg_bitstart, ((size_t)segs + 1) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&e->seg_ffstart, ((size_t)segs + 1) * sizeof(uint64_t)));
+    e->max_w = max_w; e->max_h = max_h; e->max_segs = segs;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_width, int32_t max_height) {
+    if (!out || max_width <= 0 || max_height <= 0 || max_width > 65535 || max_height > 65535) return JPEGAMD_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "jpegamd: no HIP device available (this library has no CPU path)\n");
+        return JPEGAMD_ERR_NO_DEVICE;
+    }
+    JpegAmdEncoder *e = new (std::nothrow) JpegAmdEncoder();
+    if (!e) return JPEGAMD_ERR_HIP;
+    HIP_TRY(hipGetDevice(&e->device));
+    int32_t rc = alloc_scratch(e, max_width, max_height);
+    if (rc) { jpegamd_encoder_destroy(e); return rc; }
+    HIP_TRY(hipMalloc((void **)&e->huff, 272 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->prefix, 512));
+    HIP_TRY(hipMalloc((void **)&e->status, 16));
+    HIP_TRY(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
+    HIP_TRY(hipHostMalloc((void **)&e->mirror, sizeof(*e->mirror), hipHostMallocDefault));
+    std::memset(e->mirror, 0, sizeof(*e->mirror));
+    uint32_t words[272];
+    build_huffman_words(words);
+    HIP_TRY(hipMemcpy(e->huff, words, sizeof(words), hipMemcpyHostToDevice));
+    for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+    *out = e;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
+    if (!e) return JPEGAMD_OK;
+    if (e->pending) hipStreamSynchronize(e->last_stream);
+    free_scratch(e);
+    hipFree(e->huff); hipFree(e->prefix); hipFree(e->status); hipFree(e->stats_dev);
+    if (e->mirror) hipHostFree(e->mirror);
+    for (auto &ev : e->ev) if (ev) hipEventDestroy(ev);
+    delete e;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *e, int32_t enabled) {
+    if (!e) return JPEGAMD_ERR_ARG;
+    e->profiling = enabled != 0;
+    return JPEGAMD_OK;
+}
+
+static int32_t prepare_constants(JpegAmdEncoder *e, const JpegAmdImage *img, bool need_prefix) {
+    const int q = (img->quality <= 0) ? 50 : (img->quality > 100 ? 100 : img->quality);
+    if (q != e->cur_quality) {
+        quant_table_for_quality(q, e->qtable);
+        derive_quant_consts(e->qtable, &e->qc, nullptr);
+        e->cur_quality = q;
+    }
+    if (need_prefix && (e->prefix_w != img->width || e->prefix_h != img->height || e->prefix_q != q)) {
+        uint8_t hdr[JPEGAMD_JFIF_PREFIX_BYTES];
+        build_jfif_prefix(img->width, img->height, e->qtable, hdr);
+        if (e->pending) HIP_TRY(hipStreamSynchronize(e->last_stream));
+        HIP_TRY(hipMemcpy(e->prefix, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+        e->prefix_w = img->width; e->prefix_h = img->height; e->prefix_q = q;
+    }
+    return JPEGAMD_OK;
+}
+
+static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageDesc *d) {
+    if (!img || !img->pixels || img->width <= 0 || img->height <= 0 || img->width > 65535 || img->height > 65535)
+        return JPEGAMD_ERR_ARG;
+    if (img->row_stride < 3 * img->width) return JPEGAMD_ERR_ARG;
+    if (img->channel_order != JPEGAMD_ORDER_BGR && img->channel_order != JPEGAMD_ORDER_RGB) return JPEGAMD_ERR_ARG;
+    d->pixels = (const uint8_t *)img->pixels;
+    d->width = img->width; d->height = img->height; d->row_stride = img->row_stride;
+    d->bottom_up = img->bottom_up ? 1 : 0;
+    // Y = (77 R + 150 G + 29 B) >> 8 (natural_c/src/core/converter.c:51); weights follow the STORED byte order.
+    d->weights = img->channel_order == JPEGAMD_ORDER_BGR ? (29u | (150u << 8) | (77u << 16))
+                                                         : (77u | (150u << 8) | (29u << 16));
+    d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row);
+    d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0) ? 1 : 0;
+    if (e && d->num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
+    return JPEGAMD_OK;
+}
+
+static TransformOut transform_out(const JpegAmdEncoder *e) {
+    TransformOut t;
+    std::memset(&t, 0, sizeof(t));
+    t.seg_words = e->seg_words; t.seg_bits = e->seg_bits; t.seg_syms = e->seg_syms; t.seg_exact = e->seg_exact;
+    t.ovf_words = e->ovf_words; t.huff = e->huff;
+    return t;
+}
+
+extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *img, void *out_dev,
+                                        uint64_t out_capacity, uint64_t *out_size_dev, int32_t with_container,
+                                        void *stream_) {
+    if (!e || !out_dev || !out_size_dev) return JPEGAMD_ERR_ARG;
+    ImageDesc im;
+    int32_t rc = describe(e, img, &im);
+    if (rc) return rc;
+    rc = prepare_constants(e, img, with_container != 0);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+
+    HIP_TRY(hipMemsetAsync(e->status, 0, 16, stream));
+    const bool timed = e->profiling;
+    if (timed) HIP_TRY(hipEventRecord(e->ev[0], stream));
+    TransformOut to = transform_out(e);
+    if (launch_transform(im, e->qc, to, false, stream)) return JPEGAMD_ERR_HIP;
+    if (timed) HIP_TRY(hipEventRecord(e->ev[1], stream));
+    if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
+        return JPEGAMD_ERR_HIP;
+
+    PackArgs pa;
+    std::memset(&pa, 0, sizeof(pa));
+    pa.seg_words = e->seg_words; pa.seg_bits = e->seg_bits; pa.seg_bitstart = e->seg_bitstart;
+    pa.seg_ff = e->seg_ff; pa.seg_ffstart = e->seg_ffstart; pa.num_segs = im.num_segs;
+    pa.out = (uint8_t *)out_dev; pa.out_capacity = out_capacity; pa.out_size = out_size_dev; pa.status = e->status;
+    pa.prefix = e->prefix; pa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
+    pa.write_eoi = with_container ? 1 : 0;
+    if (launch_count_ff(pa, stream)) return JPEGAMD_ERR_HIP;
+    if (launch_scan_ff(e->seg_ff, e->seg_ffstart, im.num_segs, e->stats_dev, stream)) return JPEGAMD_ERR_HIP;
+    if (timed) HIP_TRY(hipEventRecord(e->ev[2], stream));
+    if (launch_pack(pa, stream)) return JPEGAMD_ERR_HIP;
+    if (timed) HIP_TRY(hipEventRecord(e->ev[3], stream));
+
+    HIP_TRY(hipMemcpyAsync(&e->mirror->stats, e->stats_dev, sizeof(ScanStats), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&e->mirror->out_size, out_size_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&e->mirror->status, e->status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    e->last_stream = stream;
+    e->pending = true;
+    e->timed = timed;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_encoder_finish(JpegAmdEncoder *e, JpegAmdStats *stats) {
+    if (!e) return JPEGAMD_ERR_ARG;
+    if (!e->pending) return JPEGAMD_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(e->last_stream));
+    e->pending = false;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->jfif_bytes = e->mirror->out_size;
+        stats->entropy_bits = e->mirror->stats.total_bits;
+        stats->stuffed_bytes = e->mirror->stats.total_ff;
+        stats->exact_fallbacks = e->mirror->stats.total_exact;
+        if (e->timed) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev[0], e->ev[1])); stats->ns_transform = (uint64_t)(ms * 1e6);
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); stats->ns_scan = (uint64_t)(ms * 1e6);
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); stats->ns_pack = (uint64_t)(ms * 1e6);
+            HIP_TRY(hipEventElapsedTime(&ms, e->ev[0], e->ev[3])); stats->ns_total = (uint64_t)(ms * 1e6);
+        }
+    }
+    return (e->mirror->status & 1u) ? JPEGAMD_ERR_HUFF_CAPACITY : JPEGAMD_OK;
+}
+
+// Symbols coded by the last finished call (DTO rle_count).
+static uint64_t last_symbol_count(const JpegAmdEncoder *e) { return e->mirror->stats.total_syms; }
+
+extern "C" int32_t jpegamd_debug_stages(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t *y_centered,
+                                        int16_t *quant_zigzag, uint64_t *exact_mask) {
+    if (!e) return JPEGAMD_ERR_ARG;
+    ImageDesc im;
+    int32_t rc = describe(e, img, &im);
+    if (rc) return rc;
+    rc = prepare_constants(e, img, false);
+    if (rc) return rc;
+    TransformOut to = transform_out(e);
+    to.tap_y = y_centered; to.tap_zz = quant_zigzag; to.tap_mask = exact_mask;
+    if (launch_transform(im, e->qc, to, true, nullptr)) return JPEGAMD_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_debug_dct_exact(JpegAmdEncoder *e, const int8_t *blocks, float *coeffs, int64_t nblocks) {
+    if (!e || !blocks || !coeffs || nblocks < 0) return JPEGAMD_ERR_ARG;
+    if (launch_dct_exact(blocks, coeffs, nblocks, nullptr)) return JPEGAMD_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return JPEGAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Level 2: JpegCompression_Init / convertToJpeg
+// ---------------------------------------------------------------------------------------
+static std::mutex g_mu;
+static JpegAmdEncoder *g_ctx = nullptr;
+static uint64_t *g_size_dev = nullptr;
+
+static int32_t ensure_ctx(int w, int h) {
+    if (g_ctx && segs_for(w, h, nullptr, nullptr, nullptr) <= g_ctx->max_segs) return JPEGAMD_OK;
+    int mw = w, mh = h;
+    if (g_ctx) {
+        if (g_ctx->max_w > mw) mw = g_ctx->max_w;
+        if (g_ctx->max_h > mh) mh = g_ctx->max_h;
+        jpegamd_encoder_destroy(g_ctx);
+        g_ctx = nullptr;
+    }
+    int32_t rc = jpegamd_encoder_create(&g_ctx, mw, mh);
+    if (rc) return rc;
+    if (!g_size_dev) HIP_TRY(hipMalloc((void **)&g_size_dev, 16));
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t JpegCompression_Init(void) {
+    // dsp_port/jpeg_compression/src/jpeg_compression.c:18-33: 0 on success.
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx) return 0;
+    const char *env = std::getenv("JPEGAMD_INIT_DIM");
+    int dim = env ? std::atoi(env) : 2048;
+    if (dim <= 0) dim = 2048;
+    return ensure_ctx(dim, dim);
+}
+
+extern "C" int32_t JpegCompression_Reserve(int32_t max_width, int32_t max_height) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (max_width <= 0 || max_height <= 0) return JPEGAMD_ERR_ARG;
+    return ensure_ctx(max_width, max_height);
+}
+
+extern "C" int32_t JpegCompression_DeInit(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx) { jpegamd_encoder_destroy(g_ctx); g_ctx = nullptr; }
+    if (g_size_dev) { hipFree(g_size_dev); g_size_dev = nullptr; }
+    return 0;
+}
+
+// Shared by convertToJpeg and the natural_c-shaped host functions (host_compat.cpp).
+namespace jpegamd {
+JpegAmdEncoder *shared_context(int w, int h, uint64_t **size_dev) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (ensure_ctx(w, h) != JPEGAMD_OK) return nullptr;
+    if (size_dev) *size_dev = g_size_dev;
+    return g_ctx;
+}
+}  // namespace jpegamd
+
+namespace jpegamd {
+// Block (0,0) through the stage taps: centred luma, exact-order DCT, quantised zigzag.
+int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64], float dct[64], int16_t zz[64]) {
+    ImageDesc im;
+    int32_t rc = describe(nullptr, img, &im);
+    if (rc) return rc;
+    rc = prepare_constants(e, img, false);
+    if (rc) return rc;
+    im.blocks_w = 1; im.blocks_h = 1; im.segs_per_row = 1; im.num_segs = 1;   // block (0,0) only
+    int8_t *y_dev = nullptr; int16_t *zz_dev = nullptr; float *dct_dev = nullptr;
+    HIP_TRY(hipMalloc((void **)&y_dev, 64));
+    HIP_TRY(hipMalloc((void **)&zz_dev, 128));
+    HIP_TRY(hipMalloc((void **)&dct_dev, 256));
+    TransformOut to = transform_out(e);
+    to.tap_y = y_dev; to.tap_zz = zz_dev;
+    int err = launch_transform(im, e->qc, to, true, nullptr);
+    if (!err) err = launch_dct_exact(y_dev, dct_dev, 1, nullptr);
+    if (!err) err = (int)hipMemcpy(y, y_dev, 64, hipMemcpyDeviceToHost);
+    if (!err) err = (int)hipMemcpy(zz, zz_dev, 128, hipMemcpyDeviceToHost);
+    if (!err) err = (int)hipMemcpy(dct, dct_dev, 256, hipMemcpyDeviceToHost);
+    hipFree(y_dev); hipFree(zz_dev); hipFree(dct_dev);
+    return err ? JPEGAMD_ERR_HIP : JPEGAMD_OK;
+}
+}  // namespace jpegamd
+
+extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
+    if (!dto) return JPEGAMD_ERR_ARG;
+    if (!g_ctx) return JPEGAMD_ERR_NOT_INIT;
+    if (dto->gb_phy_ptr != 0 || dto->rle_phy_ptr != 0) return JPEGAMD_ERR_ARG;
+    uint64_t *size_dev = nullptr;
+    JpegAmdEncoder *e = shared_context(dto->width > 0 ? dto->width : 1, dto->height > 0 ? dto->height : 1, &size_dev);
+    if (!e) return JPEGAMD_ERR_NO_DEVICE;
+
+    JpegAmdImage img;
+    img.pixels = (const void *)(uintptr_t)dto->r_phy_ptr;
+    img.width = dto->width; img.height = dto->height; img.row_stride = dto->row_stride;
+    img.bottom_up = dto->bottom_up; img.channel_order = dto->channel_order; img.quality = dto->quality;
+
+    const bool was_profiling = e->profiling;
+    e->profiling = true;
+    int32_t rc = jpegamd_encode_async(e, &img, (void *)(uintptr_t)dto->huff_phy_ptr, dto->huff_size, size_dev, 0, nullptr);
+    JpegAmdStats st;
+    if (rc == JPEGAMD_OK) rc = jpegamd_encoder_finish(e, &st);
+    e->profiling = was_profiling;
+    if (rc != JPEGAMD_OK) return rc;   // -8 when huff_size was too small (jpeg_compression.c:205-206)
+
+    dto->huff_size = (uint32_t)st.jfif_bytes;
+    dto->rle_count = (uint32_t)last_symbol_count(e);
+    dto->cycles_color_conversion = 0;
+    dto->cycles_dct = st.ns_transform;
+    dto->cycles_quantization = 0;
+    dto->cycles_zigzag = 0;
+    dto->cycles_rle = 0;
+    dto->cycles_huffman = st.ns_scan + st.ns_pack;
+    dto->cycles_total = st.ns_total;
+
+    // First-block debug taps (jpeg_compression.c:150-169), host pointers.
+    if (dto->y_phy_ptr || dto->dct_phy_ptr || dto->quant_phy_ptr || dto->zigzag_phy_ptr) {
+        int8_t y[64]; int16_t zz[64]; float dct[64];
+        rc = first_block_taps(e, &img, y, dct, zz);
+        if (rc) return rc;
+        if (dto->y_phy_ptr) std::memcpy((void *)(uintptr_t)dto->y_phy_ptr, y, 64);
+        if (dto->dct_phy_ptr) std::memcpy((void *)(uintptr_t)dto->dct_phy_ptr, dct, 256);
+        if (dto->zigzag_phy_ptr) std::memcpy((void *)(uintptr_t)dto->zigzag_phy_ptr, zz, 128);
+        if (dto->quant_phy_ptr) {
+            int16_t raster[64];
+            for (int i = 0; i < 64; ++i) raster[kZigzagHost[i]] = zz[i];
+            std::memcpy((void *)(uintptr_t)dto->quant_phy_ptr, raster, 128);
+        }
+    }
+    return 0;
+}
+
+extern "C" int32_t JpegCompression_RemoteServiceHandler(char *service_name, uint32_t cmd, void *prm, uint32_t prm_size,
+                                                        uint32_t flags) {
+    // dsp_port/jpeg_compression/src/jpeg_compression.c:6-14: cast and forward.
+    (void)service_name; (void)cmd; (void)flags;
+    if (!prm || prm_size < sizeof(JPEG_COMPRESSION_DTO)) return JPEGAMD_ERR_ARG;
+    return convertToJpeg((JPEG_COMPRESSION_DTO *)prm);
+}

@@ -1,0 +1,104 @@
+// jpegamd_internal.h -- shared between the HIP kernels and the C-ABI host layer.
+// Not installed; the public surface is include/jpeg_compression.h.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+struct JpegAmdEncoder;
+struct JpegAmdImage;
+
+namespace jpegamd {
+
+// ---- geometry of the device pipeline ---------------------------------------------------
+// A "segment" is the unit of bitstream ownership: up to 64 consecutive 8x8 blocks of one
+// block row, processed by ONE wavefront (one block per lane).
+constexpr int kSegBlocks = 64;
+constexpr int kWavesPerGroup = 4;                    // 256-thread workgroups
+// Worst case bits per block: DC 9+11, 63 x (16+11) AC (quality 100 -> 11-bit amplitudes).
+constexpr int kMaxBlockBits = 20 + 63 * 27;          // 1721
+constexpr int kMaxBlockWords = (kMaxBlockBits + 31) / 32 + 1;   // 55 (+1: window reads)
+constexpr int kPrivWords = 15;                       // per-lane bit words kept in LDS
+constexpr int kOvfWords = kMaxBlockWords - kPrivWords + 1;      // rest spills to HBM
+constexpr int kSegCapWords = ((kSegBlocks * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64;   // 3456
+
+// Per-coefficient constants of the fast path, raster order k = u*8+v (see quant_consts.cpp).
+struct QuantConsts {
+    float mult[64];    // M_k = K_k / (q_k * G_k): AAN output -> z = coef / q
+    float bias[64];    // delta_k + 0.5
+    float thr[64];     // 2 * delta_k
+    float qstep[64];   // (float) q_k, for the exact path (quantization.c:35)
+};
+
+struct ImageDesc {
+    const uint8_t *pixels;
+    int32_t width, height, row_stride, bottom_up;
+    uint32_t weights;          // luma weights for stored bytes 0,1,2 (byte 3 = 0)
+    int32_t blocks_w, blocks_h, segs_per_row, num_segs;
+    int32_t fast_ok;           // pixels % 4 == 0 && row_stride % 4 == 0
+};
+
+struct TransformOut {
+    uint32_t *seg_words;       // [num_segs][kSegCapWords] MSB-first bit words
+    uint32_t *seg_bits;        // [num_segs]
+    uint32_t *seg_syms;        // [num_segs] run/size symbols coded (DTO rle_count)
+    uint32_t *seg_exact;       // [num_segs] coefficients recomputed in exact order
+    uint32_t *ovf_words;       // [num_segs][kOvfWords][64] private-word overflow
+    const uint32_t *huff;      // [256] AC (len<<16|code) + [16] DC
+    // stage taps (debug variant only)
+    int8_t *tap_y;
+    int16_t *tap_zz;
+    uint64_t *tap_mask;
+};
+
+struct PackArgs {
+    const uint32_t *seg_words;
+    const uint32_t *seg_bits;
+    const uint64_t *seg_bitstart;   // [num_segs+1]
+    uint32_t *seg_ff;               // [num_segs] (count kernel output)
+    const uint64_t *seg_ffstart;    // [num_segs+1]
+    int32_t num_segs;
+    uint8_t *out;
+    uint64_t out_capacity;
+    uint64_t *out_size;             // device
+    uint32_t *status;               // device: bit0 = capacity overflow
+    const uint8_t *prefix;          // 328-byte JFIF prefix template (device) or null
+    int32_t prefix_len;             // 0 or 328
+    int32_t write_eoi;
+};
+
+struct ScanStats {                   // device-side totals written by the scan kernel
+    uint64_t total_bits;
+    uint64_t total_syms;
+    uint64_t total_exact;
+    uint64_t total_ff;
+};
+
+// ---- launchers (jpegamd_kernels.hip) ---------------------------------------------------
+// All take a hipStream_t as void* and return a hipError_t as int.
+int launch_transform(const ImageDesc &im, const QuantConsts &qc, const TransformOut &out,
+                     bool taps, void *stream);
+int launch_scan_bits(const uint32_t *seg_bits, const uint32_t *seg_syms, const uint32_t *seg_exact,
+                     uint64_t *seg_bitstart, int num_segs, ScanStats *stats, void *stream);
+int launch_count_ff(const PackArgs &a, void *stream);
+int launch_scan_ff(const uint32_t *seg_ff, uint64_t *seg_ffstart, int num_segs, ScanStats *stats,
+                   void *stream);
+int launch_pack(const PackArgs &a, void *stream);
+int launch_dct_exact(const int8_t *blocks, float *coeffs, int64_t nblocks, void *stream);
+
+// ---- host-side constant derivation (quant_consts.cpp) ----------------------------------
+void quant_table_for_quality(int quality, uint8_t table[64]);
+void derive_quant_consts(const uint8_t table[64], QuantConsts *qc, double delta_out[64]);
+void build_huffman_words(uint32_t words[272]);
+size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]);
+
+extern const uint8_t kZigzagHost[64];
+
+// Process-wide context behind JpegCompression_Init / convertToJpeg / saveJPEGGrayscale
+// (jpegamd_api.cpp); grows to fit w x h.  Returns nullptr without a usable HIP device.
+::JpegAmdEncoder *shared_context(int w, int h, uint64_t **size_dev);
+// Block (0,0) stage taps (host outputs): centred luma, exact-order DCT, quantised zigzag.
+int32_t first_block_taps(::JpegAmdEncoder *e, const struct ::JpegAmdImage *img, int8_t y[64], float dct[64],
+                         int16_t zz[64]);
+
+}  // namespace jpegamd

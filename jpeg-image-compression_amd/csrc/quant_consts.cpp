@@ -1,0 +1,210 @@
+// quant_consts.cpp -- host-side derivation of the kernel's per-coefficient constants.
+//
+// For each coefficient k = u*8+v the fused kernel evaluates  zc = aan_k * M_k + (delta_k + 0.5)
+// and trusts floor(zc) as the reference's  roundf(F[u][v] / q)  only when fract(zc) > 2*delta_k.
+// delta_k must bound |z_fast - r_ref| rigorously, where r_ref is the float32 value the
+// reference divides-and-rounds (natural_c/src/core/dct.c:63-96, quantization.c:34-36):
+//
+//   delta_k = (K_k/q_k) * (E_ref_k + E_lut_k)  +  (K_k/(q_k*G_k)) * E_aan_k  +  4u*(zmax_k + 1)
+//
+//   E_ref_k  reference evaluation error: two roundings per product, one per sequential add,
+//            worst case over |p| <= 128 with the actual |COS_LUT products| as weights
+//   E_lut_k  six-decimal LUT vs the true cosines the fast path uses
+//   E_aan_k  first-order forward error bound of the float32 AAN flow graph, every add and
+//            multiply rounded separately (FMA contraction only lowers the true error)
+//   last     rounding of M_k, of the fma, and of the reference's final scale and division
+//
+// tools/derive_guard.py holds the same derivation in Python; tests compare the two and
+// tests/test_guard_band.py checks the bound against brute-force float32 emulation.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "jpegamd_internal.h"
+
+namespace jpegamd {
+
+const uint8_t kZigzagHost[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// Annex-K luminance table, raster order (natural_c/src/core/jpeg_tables.c:3-12).
+static const uint8_t kBaseQuant[64] = {
+    16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+    14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+    18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+    49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+
+// Huffman specs (natural_c/src/core/jpeg_tables.c:14-48).
+static const uint8_t kDcCounts[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+static const uint8_t kDcSymbols[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t kAcCounts[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7D};
+static const uint8_t kAcSymbols[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51,
+    0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xA1, 0x08, 0x23, 0x42, 0xB1, 0xC1,
+    0x15, 0x52, 0xD1, 0xF0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0A, 0x16, 0x17, 0x18,
+    0x19, 0x1A, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2A, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39,
+    0x3A, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4A, 0x53, 0x54, 0x55, 0x56, 0x57,
+    0x58, 0x59, 0x5A, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6A, 0x73, 0x74, 0x75,
+    0x76, 0x77, 0x78, 0x79, 0x7A, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8A, 0x92,
+    0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9A, 0xA2, 0xA3, 0xA4, 0xA5, 0xA6, 0xA7,
+    0xA8, 0xA9, 0xAA, 0xB2, 0xB3, 0xB4, 0xB5, 0xB6, 0xB7, 0xB8, 0xB9, 0xBA, 0xC2, 0xC3,
+    0xC4, 0xC5, 0xC6, 0xC7, 0xC8, 0xC9, 0xCA, 0xD2, 0xD3, 0xD4, 0xD5, 0xD6, 0xD7, 0xD8,
+    0xD9, 0xDA, 0xE1, 0xE2, 0xE3, 0xE4, 0xE5, 0xE6, 0xE7, 0xE8, 0xE9, 0xEA, 0xF1, 0xF2,
+    0xF3, 0xF4, 0xF5, 0xF6, 0xF7, 0xF8, 0xF9, 0xFA};
+
+// COS_LUT[x][u] as the float32 literals of natural_c/src/core/dct.c:9-18.
+static const float kCosLut[8][8] = {
+    {1.000000f, 0.980785f, 0.923880f, 0.831470f, 0.707107f, 0.555570f, 0.382683f, 0.195090f},
+    {1.000000f, 0.831470f, 0.382683f, -0.195090f, -0.707107f, -0.980785f, -0.923880f, -0.555570f},
+    {1.000000f, 0.555570f, -0.382683f, -0.980785f, -0.707107f, 0.195090f, 0.923880f, 0.831470f},
+    {1.000000f, 0.195090f, -0.923880f, -0.555570f, 0.707107f, 0.831470f, -0.382683f, -0.980785f},
+    {1.000000f, -0.195090f, -0.923880f, 0.555570f, 0.707107f, -0.831470f, -0.382684f, 0.980785f},
+    {1.000000f, -0.555570f, -0.382684f, 0.980785f, -0.707107f, -0.195090f, 0.923880f, -0.831470f},
+    {1.000000f, -0.831470f, 0.382684f, 0.195091f, -0.707107f, 0.980785f, -0.923879f, 0.555570f},
+    {1.000000f, -0.980785f, 0.923880f, -0.831470f, 0.707107f, -0.555570f, 0.382684f, -0.195090f}};
+
+void quant_table_for_quality(int quality, uint8_t table[64]) {
+    // quality 0/50 -> the reference's table; otherwise libjpeg scaling (extension).
+    if (quality <= 0) quality = 50;
+    if (quality > 100) quality = 100;
+    const int s = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    for (int i = 0; i < 64; ++i) {
+        int q = (kBaseQuant[i] * s + 50) / 100;
+        if (q < 1) q = 1;
+        if (q > 255) q = 255;
+        table[i] = (uint8_t)q;
+    }
+}
+
+void build_huffman_words(uint32_t words[272]) {
+    // Canonical codes (natural_c/src/core/huffman.c:89-104) packed as len<<16 | code.
+    // Symbols the spec does not list stay 0 (length 0: the reference emits no code bits
+    // for them, huffman.c:36).
+    std::memset(words, 0, 272 * sizeof(uint32_t));
+    auto fill = [](const uint8_t counts[16], const uint8_t *symbols, uint32_t *dst) {
+        uint32_t code = 0;
+        int idx = 0;
+        for (int len = 1; len <= 16; ++len) {
+            for (int i = 0; i < counts[len - 1]; ++i) dst[symbols[idx++]] = ((uint32_t)len << 16) | (code++ & 0xFFFFu);
+            code <<= 1;
+        }
+    };
+    fill(kAcCounts, kAcSymbols, words);
+    fill(kDcCounts, kDcSymbols, words + 256);
+}
+
+size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]) {
+    // natural_c/src/io/jpeg_handler.c:7-110 (byte layout of the six marker segments).
+    uint8_t *p = out;
+    auto be16 = [&](unsigned v) { *p++ = (uint8_t)(v >> 8); *p++ = (uint8_t)v; };
+    be16(0xFFD8); be16(0xFFE0); be16(16);
+    std::memcpy(p, "JFIF", 5); p += 5;
+    be16(0x0101); *p++ = 1; be16(96); be16(96); *p++ = 0; *p++ = 0;
+    be16(0xFFDB); be16(67); *p++ = 0;
+    for (int i = 0; i < 64; ++i) *p++ = table[kZigzagHost[i]];
+    be16(0xFFC0); be16(11); *p++ = 8; be16((uint16_t)height); be16((uint16_t)width);
+    *p++ = 1; *p++ = 1; *p++ = 0x11; *p++ = 0;
+    be16(0xFFC4); be16(31); *p++ = 0x00;
+    std::memcpy(p, kDcCounts, 16); p += 16; std::memcpy(p, kDcSymbols, 12); p += 12;
+    be16(0xFFC4); be16(181); *p++ = 0x10;
+    std::memcpy(p, kAcCounts, 16); p += 16; std::memcpy(p, kAcSymbols, 162); p += 162;
+    be16(0xFFDA); be16(8); *p++ = 1; *p++ = 1; *p++ = 0; *p++ = 0; *p++ = 63; *p++ = 0;
+    return (size_t)(p - out);
+}
+
+// ---- forward error analysis of the AAN flow graph ------------------------------------------
+namespace {
+constexpr double kU = 5.9604644775390625e-08;   // 2^-24
+constexpr double kPmax = 128.0;
+
+struct Tracked {
+    double f[64];   // the exact linear functional of the 64 inputs this value represents
+    double e;       // bound on |float32 value - exact functional|
+    double bound() const { double s = 0; for (double x : f) s += std::fabs(x); return kPmax * s; }
+};
+
+Tracked combine(const Tracked &a, const Tracked &b, double sb) {
+    Tracked r;
+    for (int i = 0; i < 64; ++i) r.f[i] = a.f[i] + sb * b.f[i];
+    const double ein = a.e + b.e;
+    r.e = ein + kU * (r.bound() + ein) * 1.0000001;
+    return r;
+}
+Tracked add(const Tracked &a, const Tracked &b) { return combine(a, b, 1.0); }
+Tracked sub(const Tracked &a, const Tracked &b) { return combine(a, b, -1.0); }
+Tracked scale(const Tracked &a, double c) {
+    Tracked r;
+    for (int i = 0; i < 64; ++i) r.f[i] = a.f[i] * c;
+    const double ein = std::fabs(c) * a.e;
+    r.e = ein + 2.0 * kU * (r.bound() + ein) * 1.0000001;   // rounded constant, rounded product
+    return r;
+}
+
+void aan8_tracked(Tracked *d[8]) {
+    const double A1 = std::sqrt(0.5), A2 = std::cos(3 * M_PI / 8) * std::sqrt(2.0),
+                 A4 = std::cos(M_PI / 8) * std::sqrt(2.0), A5 = std::cos(3 * M_PI / 8);
+    Tracked t0 = add(*d[0], *d[7]), t7 = sub(*d[0], *d[7]);
+    Tracked t1 = add(*d[1], *d[6]), t6 = sub(*d[1], *d[6]);
+    Tracked t2 = add(*d[2], *d[5]), t5 = sub(*d[2], *d[5]);
+    Tracked t3 = add(*d[3], *d[4]), t4 = sub(*d[3], *d[4]);
+    Tracked e0 = add(t0, t3), e3 = sub(t0, t3), e1 = add(t1, t2), e2 = sub(t1, t2);
+    Tracked o_0 = add(e0, e1), o_4 = sub(e0, e1);
+    Tracked z1 = scale(add(e2, e3), A1);
+    Tracked o_2 = add(e3, z1), o_6 = sub(e3, z1);
+    Tracked q0 = add(t4, t5), q1 = add(t5, t6), q2 = add(t6, t7);
+    Tracked z5 = scale(sub(q0, q2), A5);
+    Tracked z2 = add(scale(q0, A2), z5), z4 = add(scale(q2, A4), z5);
+    Tracked z3 = scale(q1, A1);
+    Tracked z11 = add(t7, z3), z13 = sub(t7, z3);
+    *d[5] = add(z13, z2); *d[3] = sub(z13, z2); *d[1] = add(z11, z4); *d[7] = sub(z11, z4);
+    *d[0] = o_0; *d[4] = o_4; *d[2] = o_2; *d[6] = o_6;
+}
+}  // namespace
+
+void derive_quant_consts(const uint8_t table[64], QuantConsts *qc, double delta_out[64]) {
+    std::vector<Tracked> d(64);
+    for (int i = 0; i < 64; ++i) { std::memset(d[i].f, 0, sizeof(d[i].f)); d[i].f[i] = 1.0; d[i].e = 0.0; }
+    for (int r = 0; r < 8; ++r) { Tracked *p[8]; for (int c = 0; c < 8; ++c) p[c] = &d[r * 8 + c]; aan8_tracked(p); }
+    for (int c = 0; c < 8; ++c) { Tracked *p[8]; for (int r = 0; r < 8; ++r) p[r] = &d[r * 8 + c]; aan8_tracked(p); }
+
+    for (int k = 0; k < 64; ++k) {
+        const int u = k >> 3, v = k & 7;
+        double t_true[64], t_lut[64];
+        int imax = 0;
+        for (int x = 0; x < 8; ++x)
+            for (int y = 0; y < 8; ++y) {
+                t_true[x * 8 + y] = std::cos((2 * x + 1) * u * M_PI / 16) * std::cos((2 * y + 1) * v * M_PI / 16);
+                t_lut[x * 8 + y] = (double)kCosLut[x][u] * (double)kCosLut[y][v];
+                if (std::fabs(t_true[x * 8 + y]) > std::fabs(t_true[imax])) imax = x * 8 + y;
+            }
+        const double G = d[k].f[imax] / t_true[imax];
+        const float cu = u == 0 ? 0.707107f : 1.0f, cv = v == 0 ? 0.707107f : 1.0f;
+        const double K = (double)((0.25f * cu) * cv);                 // dct.c:87-93, float32 products
+        double wsum = 0, run = 0, adds = 0, elut = 0;
+        for (int j = 0; j < 64; ++j) {
+            const double w = std::fabs(t_lut[j]);
+            wsum += w;
+            run += w;
+            if (j >= 1) adds += run;
+            elut += std::fabs(t_lut[j] - t_true[j]);
+        }
+        const double e_ref = (2.0 * kU * kPmax * wsum + kU * kPmax * adds) * 1.001;
+        const double e_lut = kPmax * elut;
+        const double e_aan = d[k].e;
+        const double q = (double)table[k];
+        const double zmax = K * kPmax * wsum / q;
+        const double delta = (K / q) * (e_ref + e_lut) + (K / (q * std::fabs(G))) * e_aan + 4.0 * kU * (zmax + 1.0);
+        qc->mult[k] = (float)(K / (q * G));
+        // Stored float32 constants must stay on the safe side of delta after rounding:
+        // need (bias - 0.5) >= delta and thr >= (bias - 0.5) + delta.  ulp(0.5) = 6e-8.
+        qc->bias[k] = (float)(0.5 + delta * 1.001 + 1.0e-7);
+        const double db = (double)qc->bias[k] - 0.5;
+        qc->thr[k] = (float)(db + delta * 1.001 + 1.0e-7);
+        qc->qstep[k] = (float)table[k];
+        if (delta_out) delta_out[k] = delta;
+    }
+}
+
+}  // namespace jpegamd

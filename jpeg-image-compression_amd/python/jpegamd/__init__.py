@@ -1,0 +1,200 @@
+"""ctypes binding of libjpegamd.so (include/jpeg_compression.h).
+
+This is plumbing for tests, bench.py and __graft_entry__: every compute call goes through
+the C-ABI into the HIP kernels.  There is no Python or CPU implementation of the codec
+here; if the shared library is missing the import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG_ROOT = Path(__file__).resolve().parents[2]          # .../jpeg-image-compression_amd
+LIB_PATH = _PKG_ROOT / "libjpegamd.so"
+HEADER_PATH = _PKG_ROOT.parent / "include" / "jpeg_compression.h"
+
+ORDER_BGR, ORDER_RGB = 0, 1
+JFIF_PREFIX_BYTES = 328
+
+ERR_NAMES = {0: "OK", -1: "ERR_ARG", -2: "ERR_NO_DEVICE", -3: "ERR_HIP", -4: "ERR_NOT_INIT", -5: "ERR_TOO_LARGE",
+             -6: "ERR_RLE_CAPACITY", -7: "ERR_BMP", -8: "ERR_HUFF_CAPACITY"}
+
+
+class JpegAmdError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{what}: {ERR_NAMES.get(code, code)} ({code})")
+        self.code = code
+
+
+class Image(C.Structure):
+    _fields_ = [("pixels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("row_stride", C.c_int32),
+                ("bottom_up", C.c_int32), ("channel_order", C.c_int32), ("quality", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("jfif_bytes", "entropy_bits", "stuffed_bytes", "exact_fallbacks",
+                                          "ns_transform", "ns_scan", "ns_pack", "ns_total")]
+
+
+class DTO(C.Structure):
+    """JPEG_COMPRESSION_DTO (dsp_port/jpeg_compression/include/jpeg_compression.h:32-64 + MI355X fields)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("r_phy_ptr", C.c_uint64), ("gb_phy_ptr", C.c_uint64),
+                ("y_phy_ptr", C.c_uint64), ("dct_phy_ptr", C.c_uint64), ("quant_phy_ptr", C.c_uint64),
+                ("zigzag_phy_ptr", C.c_uint64), ("rle_phy_ptr", C.c_uint64), ("rle_count", C.c_uint32),
+                ("huff_phy_ptr", C.c_uint64), ("huff_size", C.c_uint32),
+                ("cycles_color_conversion", C.c_uint64), ("cycles_dct", C.c_uint64),
+                ("cycles_quantization", C.c_uint64), ("cycles_zigzag", C.c_uint64), ("cycles_rle", C.c_uint64),
+                ("cycles_huffman", C.c_uint64), ("cycles_total", C.c_uint64),
+                ("row_stride", C.c_int32), ("bottom_up", C.c_int32), ("channel_order", C.c_int32),
+                ("quality", C.c_int32)]
+
+
+class BMPImage(C.Structure):
+    """natural_c/include/bmp_handler.h:37-41"""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("data", C.POINTER(C.c_uint8))]
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_PKG_ROOT}` "
+                          "(or __graft_entry__.build()); there is no fallback implementation")
+    lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
+    u64, i32, i64, vp = C.c_uint64, C.c_int32, C.c_int64, C.c_void_p
+    sig = {
+        "jpegamd_encoder_create": (i32, [C.POINTER(vp), i32, i32]),
+        "jpegamd_encoder_destroy": (i32, [vp]),
+        "jpegamd_max_jfif_bytes": (u64, [i32, i32]),
+        "jpegamd_encode_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
+        "jpegamd_encoder_finish": (i32, [vp, C.POINTER(Stats)]),
+        "jpegamd_encoder_set_profiling": (i32, [vp, i32]),
+        "jpegamd_debug_stages": (i32, [vp, C.POINTER(Image), vp, vp, vp]),
+        "jpegamd_debug_dct_exact": (i32, [vp, vp, vp, i64]),
+        "jpegamd_synth_bmp": (u64, [i32, i32, C.c_uint32, i32, C.c_uint32, vp, u64]),
+        "jpegamd_version": (C.c_char_p, []),
+        "JpegCompression_Init": (i32, []),
+        "JpegCompression_DeInit": (i32, []),
+        "JpegCompression_Reserve": (i32, [i32, i32]),
+        "convertToJpeg": (i32, [C.POINTER(DTO)]),
+        "JpegCompression_RemoteServiceHandler": (i32, [C.c_char_p, C.c_uint32, vp, C.c_uint32, C.c_uint32]),
+        "loadBMPImage": (C.POINTER(BMPImage), [C.c_char_p]),
+        "freeBMPImage": (None, [C.POINTER(BMPImage)]),
+        "saveJPEGGrayscale": (C.c_bool, [C.c_char_p, C.POINTER(BMPImage)]),
+        "jpegamd_encode_bmp_memory": (i64, [vp, u64, i32, vp, u64]),
+        "jpegamd_parse_bmp": (i32, [vp, u64, C.POINTER(Image), C.POINTER(u64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async "
+            "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_debug_stages jpegamd_debug_dct_exact "
+            "jpegamd_synth_bmp jpegamd_version JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
+            "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
+            "jpegamd_encode_bmp_memory jpegamd_parse_bmp").split()
+
+
+def version() -> str:
+    return lib.jpegamd_version().decode()
+
+
+def synth_bmp(width: int, height: int, seed: int = 1, kind: int = 0, flags: int = 0) -> bytes:
+    """Deterministic synthetic 24-bit BMP file (host code in the library; no device needed)."""
+    n = lib.jpegamd_synth_bmp(width, height, seed, kind, flags, None, 0)
+    if n == 0:
+        raise ValueError("bad synth_bmp arguments")
+    buf = (C.c_uint8 * n)()
+    got = lib.jpegamd_synth_bmp(width, height, seed, kind, flags, buf, n)
+    assert got == n
+    return bytes(buf)
+
+
+def synth_bmp_into(ptr: int, cap: int, width: int, height: int, seed: int = 1, kind: int = 0, flags: int = 0) -> int:
+    """Generate straight into caller memory (e.g. a pinned torch tensor); returns file size."""
+    return int(lib.jpegamd_synth_bmp(width, height, seed, kind, flags, C.c_void_p(ptr), cap))
+
+
+def parse_bmp(data: bytes):
+    """-> (Image view with pixels=offset, pixel_offset) using loadBMPImage's header rules."""
+    img, off = Image(), C.c_uint64(0)
+    rc = lib.jpegamd_parse_bmp(data, len(data), C.byref(img), C.byref(off))
+    if rc:
+        raise JpegAmdError(rc, "jpegamd_parse_bmp")
+    return img, off.value
+
+
+def max_jfif_bytes(width: int, height: int) -> int:
+    return int(lib.jpegamd_max_jfif_bytes(width, height))
+
+
+def encode_bmp_bytes(bmp: bytes, quality: int = 0) -> bytes:
+    """BMP file bytes -> JFIF file bytes through the device (upload, encode, download)."""
+    img, _ = parse_bmp(bmp)
+    cap = 4096 + img.width * img.height * 2
+    for _ in range(2):
+        out = (C.c_uint8 * cap)()
+        n = lib.jpegamd_encode_bmp_memory(bmp, len(bmp), quality, out, cap)
+        if n == -8:
+            cap = max_jfif_bytes(img.width, img.height)
+            continue
+        if n < 0:
+            raise JpegAmdError(int(n), "jpegamd_encode_bmp_memory")
+        return bytes(out[:n])
+    raise JpegAmdError(-8, "jpegamd_encode_bmp_memory")
+
+
+class Encoder:
+    """Level-1 context: device pointers in, device pointers out, stream-ordered."""
+
+    def __init__(self, max_width: int, max_height: int):
+        self._h = C.c_void_p()
+        rc = lib.jpegamd_encoder_create(C.byref(self._h), max_width, max_height)
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encoder_create")
+
+    def close(self):
+        if self._h:
+            lib.jpegamd_encoder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_profiling(self, on: bool):
+        lib.jpegamd_encoder_set_profiling(self._h, 1 if on else 0)
+
+    @staticmethod
+    def image(pixels_ptr: int, width: int, height: int, row_stride: int, bottom_up: bool = True,
+              channel_order: int = ORDER_BGR, quality: int = 0) -> Image:
+        return Image(pixels_ptr, width, height, row_stride, 1 if bottom_up else 0, channel_order, quality)
+
+    def encode_async(self, img: Image, out_ptr: int, out_cap: int, size_ptr: int, with_container: bool = True,
+                     stream: int = 0):
+        rc = lib.jpegamd_encode_async(self._h, C.byref(img), C.c_void_p(out_ptr), out_cap, C.c_void_p(size_ptr),
+                                      1 if with_container else 0, C.c_void_p(stream))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encode_async")
+
+    def finish(self) -> Stats:
+        st = Stats()
+        rc = lib.jpegamd_encoder_finish(self._h, C.byref(st))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encoder_finish")
+        return st
+
+    def debug_stages(self, img: Image, y_ptr: int = 0, zz_ptr: int = 0, mask_ptr: int = 0):
+        rc = lib.jpegamd_debug_stages(self._h, C.byref(img), C.c_void_p(y_ptr), C.c_void_p(zz_ptr),
+                                      C.c_void_p(mask_ptr))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_debug_stages")
+
+    def debug_dct_exact(self, blocks_ptr: int, coeffs_ptr: int, nblocks: int):
+        rc = lib.jpegamd_debug_dct_exact(self._h, C.c_void_p(blocks_ptr), C.c_void_p(coeffs_ptr), nblocks)
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_debug_dct_exact")
