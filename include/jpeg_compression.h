@@ -120,8 +120,12 @@ int32_t jpegamd_encode_async(JpegAmdEncoder *enc, const JpegAmdImage *img, void 
  * (stats may be NULL).  Returns JPEGAMD_ERR_HUFF_CAPACITY if the output did not fit. */
 int32_t jpegamd_encoder_finish(JpegAmdEncoder *enc, JpegAmdStats *stats);
 
-/* Turn per-phase hipEvent timing on/off (off by default: events cost launches). */
-int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *enc, int32_t enabled);
+/* Per-phase hipEvent timing.  slots = 0 turns it off (default).  slots = n keeps a ring of n
+ * event sets: encode call i records into slot i % n on ITS stream, so a caller can enqueue
+ * many encodes, synchronise once, and read every call's kernel times with
+ * jpegamd_encoder_profile (only the *_ns fields are filled). */
+int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *enc, int32_t slots);
+int32_t jpegamd_encoder_profile(JpegAmdEncoder *enc, int32_t slot, JpegAmdStats *stats);
 
 /* Stage taps for parity tests and the DTO's debug pointers.  Runs the same device code as
  * the hot path over the whole image and writes, for every 8x8 block in raster block order,
@@ -145,6 +149,12 @@ int32_t jpegamd_debug_dct_exact(JpegAmdEncoder *enc, const int8_t *blocks, float
  * Returns the BMP file size, or 0 if cap is too small (call with out=NULL to query). */
 uint64_t jpegamd_synth_bmp(int32_t width, int32_t height, uint32_t seed, int32_t kind,
                            uint32_t flags, uint8_t *out, uint64_t cap);
+
+/* Host-only introspection for tests: the per-coefficient fast-path constants the kernel would
+ * use for `quality` (raster order, 64 each): scale M_k, bias (0.5 + delta_k), threshold
+ * (2*delta_k) and the rigorous guard band delta_k itself.  Any pointer may be NULL. */
+int32_t jpegamd_debug_quant_consts(int32_t quality, float *mult, float *bias, float *thr, double *delta,
+                                   uint8_t *table);
 
 const char *jpegamd_version(void);
 

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "jpeg_compression.h"
 #include "jpegamd_internal.h"
@@ -32,24 +33,23 @@ struct JpegAmdEncoder {
     int max_w = 0, max_h = 0, max_segs = 0;
     // device scratch
     uint32_t *seg_words = nullptr, *seg_bits = nullptr, *seg_syms = nullptr, *seg_exact = nullptr;
-    uint32_t *seg_ff = nullptr, *ovf_words = nullptr, *huff = nullptr, *status = nullptr;
+    uint32_t *seg_ff = nullptr, *ovf_words = nullptr, *huff = nullptr;
     uint64_t *seg_bitstart = nullptr, *seg_ffstart = nullptr;
     uint8_t *prefix = nullptr;
     ScanStats *stats_dev = nullptr;
-    // host mirrors (pinned)
-    struct HostMirror {
-        ScanStats stats;
-        uint64_t out_size;
-        uint32_t status;
-    } *mirror = nullptr;
+    ScanStats mirror;            // host copy of stats_dev, fetched by finish()
     // cached constants
     int cur_quality = -1;
+    bool std_kernel = false;     // table == reference's and baked literals == derived constants
     uint8_t qtable[64];
     QuantConsts qc;
     int prefix_w = -1, prefix_h = -1, prefix_q = -1;
-    // profiling
-    bool profiling = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // profiling: a ring of event quadruples so callers can time many async encodes and read
+    // the per-kernel durations after ONE synchronisation
+    struct EventSet { hipEvent_t ev[4]; };
+    std::vector<EventSet> ring;
+    uint64_t calls = 0;          // encodes enqueued since profiling was (re)enabled
+    int last_slot = -1;
     // last call
     hipStream_t last_stream = nullptr;
     bool pending = false;
@@ -66,6 +66,21 @@ static int segs_for(int w, int h, int *bw, int *bh, int *spr) {
 }
 
 extern "C" const char *jpegamd_version(void) { return "jpegamd 0.1 (gfx950)"; }
+
+extern "C" int32_t jpegamd_debug_quant_consts(int32_t quality, float *mult, float *bias, float *thr, double *delta,
+                                              uint8_t *table) {
+    uint8_t t[64];
+    QuantConsts qc;
+    double d[64];
+    quant_table_for_quality(quality, t);
+    derive_quant_consts(t, &qc, d);
+    if (mult) std::memcpy(mult, qc.mult, sizeof(qc.mult));
+    if (bias) std::memcpy(bias, qc.bias, sizeof(qc.bias));
+    if (thr) std::memcpy(thr, qc.thr, sizeof(qc.thr));
+    if (delta) std::memcpy(delta, d, sizeof(d));
+    if (table) std::memcpy(table, t, 64);
+    return JPEGAMD_OK;
+}
 
 extern "C" uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return 0;
@@ -110,14 +125,11 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     if (rc) { jpegamd_encoder_destroy(e); return rc; }
     HIP_TRY(hipMalloc((void **)&e->huff, 272 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->prefix, 512));
-    HIP_TRY(hipMalloc((void **)&e->status, 16));
     HIP_TRY(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
-    HIP_TRY(hipHostMalloc((void **)&e->mirror, sizeof(*e->mirror), hipHostMallocDefault));
-    std::memset(e->mirror, 0, sizeof(*e->mirror));
+    std::memset(&e->mirror, 0, sizeof(e->mirror));
     uint32_t words[272];
     build_huffman_words(words);
     HIP_TRY(hipMemcpy(e->huff, words, sizeof(words), hipMemcpyHostToDevice));
-    for (auto &ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     *out = e;
     return JPEGAMD_OK;
 }
@@ -126,17 +138,39 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (!e) return JPEGAMD_OK;
     if (e->pending) hipStreamSynchronize(e->last_stream);
     free_scratch(e);
-    hipFree(e->huff); hipFree(e->prefix); hipFree(e->status); hipFree(e->stats_dev);
-    if (e->mirror) hipHostFree(e->mirror);
-    for (auto &ev : e->ev) if (ev) hipEventDestroy(ev);
+    hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev);
+    for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e;
     return JPEGAMD_OK;
 }
 
-extern "C" int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *e, int32_t enabled) {
-    if (!e) return JPEGAMD_ERR_ARG;
-    e->profiling = enabled != 0;
+extern "C" int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *e, int32_t slots) {
+    if (!e || slots < 0 || slots > 65536) return JPEGAMD_ERR_ARG;
+    if (e->pending) HIP_TRY(hipStreamSynchronize(e->last_stream));
+    for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
+    e->ring.clear();
+    e->ring.resize((size_t)slots);
+    for (auto &set : e->ring) for (auto &ev : set.ev) HIP_TRY(hipEventCreate(&ev));
+    e->calls = 0;
+    e->last_slot = -1;
     return JPEGAMD_OK;
+}
+
+static int32_t read_slot(JpegAmdEncoder *e, int slot, JpegAmdStats *stats) {
+    if (slot < 0 || (size_t)slot >= e->ring.size()) return JPEGAMD_ERR_ARG;
+    hipEvent_t *ev = e->ring[(size_t)slot].ev;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); stats->ns_transform = (uint64_t)((double)ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->ns_scan = (uint64_t)((double)ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ns_pack = (uint64_t)((double)ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3])); stats->ns_total = (uint64_t)((double)ms * 1e6);
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_encoder_profile(JpegAmdEncoder *e, int32_t slot, JpegAmdStats *stats) {
+    if (!e || !stats) return JPEGAMD_ERR_ARG;
+    std::memset(stats, 0, sizeof(*stats));
+    return read_slot(e, slot, stats);
 }
 
 static int32_t prepare_constants(JpegAmdEncoder *e, const JpegAmdImage *img, bool need_prefix) {
@@ -144,6 +178,8 @@ static int32_t prepare_constants(JpegAmdEncoder *e, const JpegAmdImage *img, boo
     if (q != e->cur_quality) {
         quant_table_for_quality(q, e->qtable);
         derive_quant_consts(e->qtable, &e->qc, nullptr);
+        const char *force = std::getenv("JPEGAMD_KERNEL");     // "generic" forces the runtime-constant kernel
+        e->std_kernel = std_consts_match_baked(e->qtable) && !(force && std::strcmp(force, "generic") == 0);
         e->cur_quality = q;
     }
     if (need_prefix && (e->prefix_w != img->width || e->prefix_h != img->height || e->prefix_q != q)) {
@@ -192,12 +228,17 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
 
-    HIP_TRY(hipMemsetAsync(e->status, 0, 16, stream));
-    const bool timed = e->profiling;
-    if (timed) HIP_TRY(hipEventRecord(e->ev[0], stream));
+    const bool timed = !e->ring.empty();
+    hipEvent_t *ev = nullptr;
+    if (timed) {
+        e->last_slot = (int)(e->calls % e->ring.size());
+        ev = e->ring[(size_t)e->last_slot].ev;
+        ++e->calls;
+        HIP_TRY(hipEventRecord(ev[0], stream));
+    }
     TransformOut to = transform_out(e);
-    if (launch_transform(im, e->qc, to, false, stream)) return JPEGAMD_ERR_HIP;
-    if (timed) HIP_TRY(hipEventRecord(e->ev[1], stream));
+    if (launch_transform(im, e->qc, to, false, e->std_kernel, stream)) return JPEGAMD_ERR_HIP;
+    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
         return JPEGAMD_ERR_HIP;
 
@@ -205,18 +246,15 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
     std::memset(&pa, 0, sizeof(pa));
     pa.seg_words = e->seg_words; pa.seg_bits = e->seg_bits; pa.seg_bitstart = e->seg_bitstart;
     pa.seg_ff = e->seg_ff; pa.seg_ffstart = e->seg_ffstart; pa.num_segs = im.num_segs;
-    pa.out = (uint8_t *)out_dev; pa.out_capacity = out_capacity; pa.out_size = out_size_dev; pa.status = e->status;
+    pa.out = (uint8_t *)out_dev; pa.out_capacity = out_capacity; pa.out_size = out_size_dev; pa.stats = e->stats_dev;
     pa.prefix = e->prefix; pa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
     pa.write_eoi = with_container ? 1 : 0;
     if (launch_count_ff(pa, stream)) return JPEGAMD_ERR_HIP;
     if (launch_scan_ff(e->seg_ff, e->seg_ffstart, im.num_segs, e->stats_dev, stream)) return JPEGAMD_ERR_HIP;
-    if (timed) HIP_TRY(hipEventRecord(e->ev[2], stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
     if (launch_pack(pa, stream)) return JPEGAMD_ERR_HIP;
-    if (timed) HIP_TRY(hipEventRecord(e->ev[3], stream));
+    if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
 
-    HIP_TRY(hipMemcpyAsync(&e->mirror->stats, e->stats_dev, sizeof(ScanStats), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&e->mirror->out_size, out_size_dev, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&e->mirror->status, e->status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     e->last_stream = stream;
     e->pending = true;
     e->timed = timed;
@@ -228,25 +266,23 @@ extern "C" int32_t jpegamd_encoder_finish(JpegAmdEncoder *e, JpegAmdStats *stats
     if (!e->pending) return JPEGAMD_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(e->last_stream));
     e->pending = false;
+    HIP_TRY(hipMemcpy(&e->mirror, e->stats_dev, sizeof(ScanStats), hipMemcpyDeviceToHost));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        stats->jfif_bytes = e->mirror->out_size;
-        stats->entropy_bits = e->mirror->stats.total_bits;
-        stats->stuffed_bytes = e->mirror->stats.total_ff;
-        stats->exact_fallbacks = e->mirror->stats.total_exact;
+        stats->jfif_bytes = e->mirror.out_size;
+        stats->entropy_bits = e->mirror.total_bits;
+        stats->stuffed_bytes = e->mirror.total_ff;
+        stats->exact_fallbacks = e->mirror.total_exact;
         if (e->timed) {
-            float ms = 0;
-            HIP_TRY(hipEventElapsedTime(&ms, e->ev[0], e->ev[1])); stats->ns_transform = (uint64_t)(ms * 1e6);
-            HIP_TRY(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); stats->ns_scan = (uint64_t)(ms * 1e6);
-            HIP_TRY(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); stats->ns_pack = (uint64_t)(ms * 1e6);
-            HIP_TRY(hipEventElapsedTime(&ms, e->ev[0], e->ev[3])); stats->ns_total = (uint64_t)(ms * 1e6);
+            int32_t rc = read_slot(e, e->last_slot, stats);
+            if (rc) return rc;
         }
     }
-    return (e->mirror->status & 1u) ? JPEGAMD_ERR_HUFF_CAPACITY : JPEGAMD_OK;
+    return (e->mirror.status & 1u) ? JPEGAMD_ERR_HUFF_CAPACITY : JPEGAMD_OK;
 }
 
 // Symbols coded by the last finished call (DTO rle_count).
-static uint64_t last_symbol_count(const JpegAmdEncoder *e) { return e->mirror->stats.total_syms; }
+static uint64_t last_symbol_count(const JpegAmdEncoder *e) { return e->mirror.total_syms; }
 
 extern "C" int32_t jpegamd_debug_stages(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t *y_centered,
                                         int16_t *quant_zigzag, uint64_t *exact_mask) {
@@ -258,7 +294,7 @@ extern "C" int32_t jpegamd_debug_stages(JpegAmdEncoder *e, const JpegAmdImage *i
     if (rc) return rc;
     TransformOut to = transform_out(e);
     to.tap_y = y_centered; to.tap_zz = quant_zigzag; to.tap_mask = exact_mask;
-    if (launch_transform(im, e->qc, to, true, nullptr)) return JPEGAMD_ERR_HIP;
+    if (launch_transform(im, e->qc, to, true, e->std_kernel, nullptr)) return JPEGAMD_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(nullptr));
     return JPEGAMD_OK;
 }
@@ -340,7 +376,7 @@ int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64
     HIP_TRY(hipMalloc((void **)&dct_dev, 256));
     TransformOut to = transform_out(e);
     to.tap_y = y_dev; to.tap_zz = zz_dev;
-    int err = launch_transform(im, e->qc, to, true, nullptr);
+    int err = launch_transform(im, e->qc, to, true, e->std_kernel, nullptr);
     if (!err) err = launch_dct_exact(y_dev, dct_dev, 1, nullptr);
     if (!err) err = (int)hipMemcpy(y, y_dev, 64, hipMemcpyDeviceToHost);
     if (!err) err = (int)hipMemcpy(zz, zz_dev, 128, hipMemcpyDeviceToHost);
@@ -363,12 +399,13 @@ extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
     img.width = dto->width; img.height = dto->height; img.row_stride = dto->row_stride;
     img.bottom_up = dto->bottom_up; img.channel_order = dto->channel_order; img.quality = dto->quality;
 
-    const bool was_profiling = e->profiling;
-    e->profiling = true;
+    if (e->ring.empty()) {
+        int32_t prc = jpegamd_encoder_set_profiling(e, 1);     // the DTO always reports stage times
+        if (prc) return prc;
+    }
     int32_t rc = jpegamd_encode_async(e, &img, (void *)(uintptr_t)dto->huff_phy_ptr, dto->huff_size, size_dev, 0, nullptr);
     JpegAmdStats st;
     if (rc == JPEGAMD_OK) rc = jpegamd_encoder_finish(e, &st);
-    e->profiling = was_profiling;
     if (rc != JPEGAMD_OK) return rc;   // -8 when huff_size was too small (jpeg_compression.c:205-206)
 
     dto->huff_size = (uint32_t)st.jfif_bytes;

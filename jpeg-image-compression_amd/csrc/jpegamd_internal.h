@@ -30,6 +30,14 @@ struct QuantConsts {
     float qstep[64];   // (float) q_k, for the exact path (quantization.c:35)
 };
 
+// Constants of the kernel specialised for the reference's table: one bias for every
+// coefficient (so it can live in a VGPR while mult/thr are instruction literals).
+struct StdConsts {
+    float mult[64];
+    float thr[64];     // (bias - 0.5) + delta_k
+    float bias;        // 0.5 + max_k delta_k
+};
+
 struct ImageDesc {
     const uint8_t *pixels;
     int32_t width, height, row_stride, bottom_up;
@@ -51,6 +59,16 @@ struct TransformOut {
     uint64_t *tap_mask;
 };
 
+struct ScanStats {                   // device-side per-call record (scan kernels + k_pack)
+    uint64_t total_bits;
+    uint64_t total_syms;
+    uint64_t total_exact;
+    uint64_t total_ff;
+    uint64_t out_size;               // copy of *out_size (k_pack)
+    uint32_t status;                 // bit0 = output capacity overflow; zeroed by the bit scan
+    uint32_t pad;
+};
+
 struct PackArgs {
     const uint32_t *seg_words;
     const uint32_t *seg_bits;
@@ -61,23 +79,17 @@ struct PackArgs {
     uint8_t *out;
     uint64_t out_capacity;
     uint64_t *out_size;             // device
-    uint32_t *status;               // device: bit0 = capacity overflow
+    ScanStats *stats;               // device: status bit0 = capacity overflow; out_size copy
     const uint8_t *prefix;          // 328-byte JFIF prefix template (device) or null
     int32_t prefix_len;             // 0 or 328
     int32_t write_eoi;
 };
 
-struct ScanStats {                   // device-side totals written by the scan kernel
-    uint64_t total_bits;
-    uint64_t total_syms;
-    uint64_t total_exact;
-    uint64_t total_ff;
-};
 
 // ---- launchers (jpegamd_kernels.hip) ---------------------------------------------------
 // All take a hipStream_t as void* and return a hipError_t as int.
 int launch_transform(const ImageDesc &im, const QuantConsts &qc, const TransformOut &out,
-                     bool taps, void *stream);
+                     bool taps, bool std_table, void *stream);
 int launch_scan_bits(const uint32_t *seg_bits, const uint32_t *seg_syms, const uint32_t *seg_exact,
                      uint64_t *seg_bitstart, int num_segs, ScanStats *stats, void *stream);
 int launch_count_ff(const PackArgs &a, void *stream);
@@ -89,6 +101,8 @@ int launch_dct_exact(const int8_t *blocks, float *coeffs, int64_t nblocks, void 
 // ---- host-side constant derivation (quant_consts.cpp) ----------------------------------
 void quant_table_for_quality(int quality, uint8_t table[64]);
 void derive_quant_consts(const uint8_t table[64], QuantConsts *qc, double delta_out[64]);
+void derive_std_consts(const uint8_t table[64], StdConsts *sc);
+bool std_consts_match_baked(const uint8_t table[64]);   // table is the reference's AND baked == derived
 void build_huffman_words(uint32_t words[272]);
 size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]);
 

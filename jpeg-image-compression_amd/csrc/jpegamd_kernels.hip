@@ -32,6 +32,8 @@
 
 namespace jpegamd {
 
+#include "std_table_consts.inc"
+
 // ------------------------------------------------------------------------------------
 // Tables
 // ------------------------------------------------------------------------------------
@@ -82,22 +84,28 @@ __device__ __forceinline__ int luma_clamped(const ImageDesc &im, int x, int y) {
     return (int)(((w & 0xFF) * p[0] + ((w >> 8) & 0xFF) * p[1] + ((w >> 16) & 0xFF) * p[2]) >> 8);
 }
 
-// 8 pixels (24 bytes, 4-byte aligned) -> 8 luma values via v_dot4_u32_u8.
-__device__ __forceinline__ void luma_row8(const uint32_t *__restrict__ src, uint32_t w, int (&y)[8]) {
+// (float) of byte 1.  Written so that hipcc selects v_cvt_f32_ubyte1 itself: an inline-asm
+// consumer right behind v_dot4 is not covered by the compiler's DOT->VALU hazard padding on
+// gfx950 and read a stale register (seen as corrupt luma on hardware).
+__device__ __forceinline__ float ubyte1_f32(uint32_t x) { return (float)(uint8_t)(x >> 8); }
+
+// 8 pixels (24 bytes, 4-byte aligned) -> 8 luma values via v_dot4_u32_u8.  The dot product is
+// 256*Y + fraction (< 2^16), so Y = byte 1 of the result: v_cvt_f32_ubyte1 converts it in one op.
+__device__ __forceinline__ void luma_row8(const uint32_t *__restrict__ src, uint32_t w, float *y) {
     const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4], d5 = src[5];
     const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu;
     const uint32_t wA = w;                         // pixel in bytes 0..2
     const uint32_t wB0 = c0 << 24, wB1 = c1 | (c2 << 8);          // byte 3 | bytes 0..1
     const uint32_t wC0 = (c0 << 16) | (c1 << 24), wC1 = c2;       // bytes 2..3 | byte 0
     const uint32_t wD = w << 8;                    // pixel in bytes 1..3
-    y[0] = (int)(__builtin_amdgcn_udot4(d0, wA, 0u, false) >> 8);
-    y[1] = (int)(__builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, 0u, false), false) >> 8);
-    y[2] = (int)(__builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, 0u, false), false) >> 8);
-    y[3] = (int)(__builtin_amdgcn_udot4(d2, wD, 0u, false) >> 8);
-    y[4] = (int)(__builtin_amdgcn_udot4(d3, wA, 0u, false) >> 8);
-    y[5] = (int)(__builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, 0u, false), false) >> 8);
-    y[6] = (int)(__builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, 0u, false), false) >> 8);
-    y[7] = (int)(__builtin_amdgcn_udot4(d5, wD, 0u, false) >> 8);
+    y[0] = ubyte1_f32(__builtin_amdgcn_udot4(d0, wA, 0u, false));
+    y[1] = ubyte1_f32(__builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, 0u, false), false));
+    y[2] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, 0u, false), false));
+    y[3] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wD, 0u, false));
+    y[4] = ubyte1_f32(__builtin_amdgcn_udot4(d3, wA, 0u, false));
+    y[5] = ubyte1_f32(__builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, 0u, false), false));
+    y[6] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, 0u, false), false));
+    y[7] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wD, 0u, false));
 }
 
 // ------------------------------------------------------------------------------------
@@ -228,8 +236,21 @@ __device__ __forceinline__ uint32_t amp_bits(int v, int nbits) {
     return (uint32_t)(v + (v >> 31)) & ((1u << nbits) - 1u);
 }
 
-template <bool kTaps>
-__global__ __launch_bounds__(64 * kWavesPerGroup) void k_transform(const ImageDesc im, const QuantConsts qc,
+// floor to int in one instruction (the compiler emits v_floor_f32 + v_cvt_i32_f32)
+__device__ __forceinline__ int cvt_floor_i32(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// kStd: constants of the reference's own table baked in as instruction literals (no scalar
+// loads in the 63 quantisation sites); otherwise they come from the kernel argument block.
+#ifndef JPEGAMD_WAVES_PER_EU
+#define JPEGAMD_WAVES_PER_EU 3
+#endif
+template <bool kTaps, bool kStd>
+__global__ __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(JPEGAMD_WAVES_PER_EU, JPEGAMD_WAVES_PER_EU)))
+void k_transform(const ImageDesc im, const QuantConsts qc,
                                                                    const TransformOut out) {
     __shared__ uint32_t s_ac[256];
     __shared__ uint32_t s_dc[16];
@@ -257,17 +278,16 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void k_transform(const ImageDe
     const int bx = bx0 + min(lane, nblk - 1);      // idle lanes shadow the last block
     const int px0 = bx * 8, py0 = by * 8;
 
-    // ---- 1. load + luma + level shift ---------------------------------------------------
+    // ---- 1. load + luma -----------------------------------------------------------------
+    // d[] holds UNSHIFTED luma (0..255).  The level shift (converter.c:84-86) only moves the
+    // DC term: every other output of the flow graph is a difference of exact integer sums, so
+    // the AC values are bit-identical with or without it, and DC = sum - 64*128 exactly.
     float d[64];
     const bool interior = im.fast_ok && ((bx0 + nblk) * 8 <= im.width) && (py0 + 8 <= im.height);
     if (interior) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            int y8[8];
-            luma_row8(reinterpret_cast<const uint32_t *>(row_ptr(im, py0 + r) + 3 * (size_t)px0), im.weights, y8);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) d[r * 8 + c] = (float)(y8[c] - 128);
-        }
+        for (int r = 0; r < 8; ++r)
+            luma_row8(reinterpret_cast<const uint32_t *>(row_ptr(im, py0 + r) + 3 * (size_t)px0), im.weights, &d[r * 8]);
     } else {
         // Edge tile (right/bottom replication, converter.c:31,36) or unaligned source:
         // byte-wise gather staged through LDS so the register file keeps static indices.
@@ -281,14 +301,14 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void k_transform(const ImageDe
         for (int g = 0; g < 16; ++g) {
             const uint32_t wv = wl.priv[g * 64 + lane];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[g * 4 + j] = (float)((int)((wv >> (8 * j)) & 0xFFu) - 128);
+            for (int j = 0; j < 4; ++j) d[g * 4 + j] = (float)((wv >> (8 * j)) & 0xFFu);
         }
     }
 
     if (kTaps && active && out.tap_y) {
         int8_t *ty = out.tap_y + ((size_t)by * im.blocks_w + bx) * 64;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) ty[i] = (int8_t)(int)d[i];
+        for (int i = 0; i < 64; ++i) ty[i] = (int8_t)((int)d[i] - 128);   // converter.c:84-86
     }
 
     // ---- 2. fast 2-D DCT ----------------------------------------------------------------
@@ -299,17 +319,21 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void k_transform(const ImageDe
 
     // ---- 3. quantise with guard band; record sites needing the exact order --------------
     int n[64];
-    // DC: d[0] is the exact integer sum of the 64 centred pixels, so the reference's
+    // DC: d[0] - 8192 is the exact integer sum of the 64 centred pixels, so the reference's
     // sequential float sum equals it and fl(K00 * S) / q reproduces dct.c:93 + quantization.c:36.
-    n[0] = ref_quantise(__fmul_rn(ref_scale(0, 0), d[0]), qc.qstep[0]);
+    n[0] = ref_quantise(__fmul_rn(ref_scale(0, 0), d[0] - 8192.0f), qc.qstep[0]);
+    const unsigned long long active_mask = __ballot(active);
+    float bias_v = kStdBias;
+    if (kStd) asm volatile("v_mov_b32 %0, %1" : "=v"(bias_v) : "s"(kStdBias));   // keep it in a VGPR
     int nev = 0;
 #pragma unroll
     for (int k = 1; k < 64; ++k) {
-        const float zc = fmaf(d[k], qc.mult[k], qc.bias[k]);     // z + 0.5 + delta_k
+        // zc = z + 0.5 + delta; floor(zc) is the rounded quotient unless fract(zc) <= thr_k,
+        // i.e. unless z is within delta_k of a tie.
+        const float zc = kStd ? fmaf(d[k], kStdMult[k], bias_v) : fmaf(d[k], qc.mult[k], qc.bias[k]);
         const float g = __builtin_amdgcn_fractf(zc);
-        n[k] = (int)floorf(zc);
-        const bool flag = active && (g <= qc.thr[k]);            // within delta_k of a tie
-        const unsigned long long m = __ballot(flag);
+        n[k] = cvt_floor_i32(zc);
+        const unsigned long long m = __ballot(g <= (kStd ? kStdThr[k] : qc.thr[k])) & active_mask;
         if (__builtin_expect(m != 0ull, 0)) {
             if (lane == 0) {
                 wl.ev_k[nev] = (uint32_t)k;
@@ -455,15 +479,14 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) void k_transform(const ImageDe
     }
 }
 
-int launch_transform(const ImageDesc &im, const QuantConsts &qc, const TransformOut &out, bool taps,
+int launch_transform(const ImageDesc &im, const QuantConsts &qc, const TransformOut &out, bool taps, bool std_table,
                      void *stream) {
-    const int groups = (im.num_segs + kWavesPerGroup - 1) / kWavesPerGroup;
-    if (taps)
-        hipLaunchKernelGGL(k_transform<true>, dim3(groups), dim3(64 * kWavesPerGroup), 0, (hipStream_t)stream, im,
-                           qc, out);
-    else
-        hipLaunchKernelGGL(k_transform<false>, dim3(groups), dim3(64 * kWavesPerGroup), 0, (hipStream_t)stream, im,
-                           qc, out);
+    const dim3 grid((im.num_segs + kWavesPerGroup - 1) / kWavesPerGroup), block(64 * kWavesPerGroup);
+    hipStream_t s = (hipStream_t)stream;
+    if (taps && std_table) hipLaunchKernelGGL((k_transform<true, true>), grid, block, 0, s, im, qc, out);
+    else if (taps) hipLaunchKernelGGL((k_transform<true, false>), grid, block, 0, s, im, qc, out);
+    else if (std_table) hipLaunchKernelGGL((k_transform<false, true>), grid, block, 0, s, im, qc, out);
+    else hipLaunchKernelGGL((k_transform<false, false>), grid, block, 0, s, im, qc, out);
     return (int)hipGetLastError();
 }
 
@@ -497,6 +520,9 @@ __device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t *s_
     return s_wave_tot[wave] + incl - v;
 }
 
+// Tiles of kScanThreads*16 elements: every thread owns 16 consecutive values (4 coalesced
+// 16-byte loads, all issued before the first use), scans them in registers, the block scans
+// the per-thread sums, and the running base carries to the next tile.
 __global__ __launch_bounds__(kScanThreads) void k_scan_segments(const uint32_t *__restrict__ in,
                                                                 const uint32_t *__restrict__ aux0,
                                                                 const uint32_t *__restrict__ aux1,
@@ -504,19 +530,49 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_segments(const uint32_t *
                                                                 ScanStats *stats, int which) {
     __shared__ uint64_t s_tot[17];
     __shared__ uint64_t s_aux[2][kScanThreads / 64];
-    const int chunk = (n + kScanThreads - 1) / kScanThreads;
-    const int begin = min(n, (int)threadIdx.x * chunk), end = min(n, begin + chunk);
-    uint64_t sum = 0, a0 = 0, a1 = 0;
-    for (int i = begin; i < end; ++i) {
-        sum += in[i];
-        if (aux0) a0 += aux0[i];
-        if (aux1) a1 += aux1[i];
+    constexpr int kPer = 16;
+    uint64_t base = 0, a0 = 0, a1 = 0;
+    for (int tile = 0; tile < n; tile += kScanThreads * kPer) {
+        const int begin = tile + (int)threadIdx.x * kPer;
+        uint32_t v[kPer];
+        if (begin + kPer <= n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(in + begin);     // hipMalloc base, begin % 16 == 0
+#pragma unroll
+            for (int j = 0; j < kPer / 4; ++j) {
+                const uint4 q = p[j];
+                v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+            }
+            if (aux0) {
+                const uint4 *pa = reinterpret_cast<const uint4 *>(aux0 + begin), *pb = reinterpret_cast<const uint4 *>(aux1 + begin);
+#pragma unroll
+                for (int j = 0; j < kPer / 4; ++j) {
+                    const uint4 qa = pa[j], qb = pb[j];
+                    a0 += (uint64_t)qa.x + qa.y + qa.z + qa.w;
+                    a1 += (uint64_t)qb.x + qb.y + qb.z + qb.w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int i = begin + j;
+                v[j] = i < n ? in[i] : 0u;
+                if (aux0 && i < n) { a0 += aux0[i]; a1 += aux1[i]; }
+            }
+        }
+        uint64_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) sum += v[j];
+        uint64_t total;
+        uint64_t run = base + block_excl_scan_u64(sum, s_tot, &total);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (begin + j < n) out[begin + j] = run;
+            run += v[j];
+        }
+        base += total;
+        __syncthreads();                       // s_tot is reused by the next tile
     }
-    uint64_t total;
-    uint64_t run = block_excl_scan_u64(sum, s_tot, &total);
-    for (int i = begin; i < end; ++i) { out[i] = run; run += in[i]; }
-    if (threadIdx.x == 0) out[n] = total;
-    // side totals
+    if (threadIdx.x == 0) out[n] = base;
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); }
@@ -525,8 +581,8 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_segments(const uint32_t *
     if (threadIdx.x == 0 && stats) {
         uint64_t t0 = 0, t1 = 0;
         for (int w = 0; w < kScanThreads / 64; ++w) { t0 += s_aux[0][w]; t1 += s_aux[1][w]; }
-        if (which == 0) { stats->total_bits = total; stats->total_syms = t0; stats->total_exact = t1; }
-        else stats->total_ff = total;
+        if (which == 0) { stats->total_bits = base; stats->total_syms = t0; stats->total_exact = t1; stats->status = 0u; }
+        else stats->total_ff = base;
     }
 }
 
@@ -641,7 +697,7 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
         }
         running += (uint32_t)__popcll(m);
     }
-    if (__any(overflow) && lane == 0) atomicOr(a.status, 1u);
+    if (__any(overflow) && lane == 0) atomicOr(&a.stats->status, 1u);
 
     if (s == a.num_segs - 1 && lane == 0) {
         uint64_t end = base + v.nown + running;
@@ -656,8 +712,9 @@ __global__ __launch_bounds__(256) void k_pack(const PackArgs a) {
             if (end + 2 <= a.out_capacity) { a.out[end] = 0xFF; a.out[end + 1] = 0xD9; } else ok = false;
             end += 2;
         }
-        if (!ok) atomicOr(a.status, 1u);
+        if (!ok) atomicOr(&a.stats->status, 1u);
         *a.out_size = end;
+        a.stats->out_size = end;
     }
 }
 

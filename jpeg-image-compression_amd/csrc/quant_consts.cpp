@@ -207,4 +207,28 @@ void derive_quant_consts(const uint8_t table[64], QuantConsts *qc, double delta_
     }
 }
 
+void derive_std_consts(const uint8_t table[64], StdConsts *sc) {
+    QuantConsts qc;
+    double delta[64];
+    derive_quant_consts(table, &qc, delta);
+    double dmax = 0;
+    for (int k = 1; k < 64; ++k) dmax = delta[k] > dmax ? delta[k] : dmax;
+    sc->bias = (float)(0.5 + dmax * 1.001 + 1.0e-7);
+    const double db = (double)sc->bias - 0.5;          // >= every delta_k
+    for (int k = 0; k < 64; ++k) {
+        sc->mult[k] = qc.mult[k];
+        sc->thr[k] = (float)(db + delta[k] * 1.001 + 1.0e-7);
+    }
+}
+
+#include "std_table_consts.inc"
+
+bool std_consts_match_baked(const uint8_t table[64]) {
+    if (std::memcmp(table, kStdTable, 64) != 0) return false;
+    StdConsts sc;
+    derive_std_consts(table, &sc);
+    return std::memcmp(sc.mult, kStdMult, sizeof(kStdMult)) == 0 && std::memcmp(sc.thr, kStdThr, sizeof(kStdThr)) == 0 &&
+           sc.bias == kStdBias;
+}
+
 }  // namespace jpegamd

@@ -68,10 +68,12 @@ def _load() -> C.CDLL:
         "jpegamd_encode_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
         "jpegamd_encoder_finish": (i32, [vp, C.POINTER(Stats)]),
         "jpegamd_encoder_set_profiling": (i32, [vp, i32]),
+        "jpegamd_encoder_profile": (i32, [vp, i32, C.POINTER(Stats)]),
         "jpegamd_debug_stages": (i32, [vp, C.POINTER(Image), vp, vp, vp]),
         "jpegamd_debug_dct_exact": (i32, [vp, vp, vp, i64]),
         "jpegamd_synth_bmp": (u64, [i32, i32, C.c_uint32, i32, C.c_uint32, vp, u64]),
         "jpegamd_version": (C.c_char_p, []),
+        "jpegamd_debug_quant_consts": (i32, [i32, vp, vp, vp, vp, vp]),
         "JpegCompression_Init": (i32, []),
         "JpegCompression_DeInit": (i32, []),
         "JpegCompression_Reserve": (i32, [i32, i32]),
@@ -91,10 +93,20 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async "
-            "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_debug_stages jpegamd_debug_dct_exact "
-            "jpegamd_synth_bmp jpegamd_version JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
+            "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
+            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
             "jpegamd_encode_bmp_memory jpegamd_parse_bmp").split()
+
+
+def quant_consts(quality: int = 50):
+    """-> dict of numpy arrays (mult, bias, thr float32[64]; delta float64[64]; table uint8[64])."""
+    import numpy as np
+    mult, bias, thr = (np.zeros(64, np.float32) for _ in range(3))
+    delta, table = np.zeros(64, np.float64), np.zeros(64, np.uint8)
+    lib.jpegamd_debug_quant_consts(quality, mult.ctypes.data, bias.ctypes.data, thr.ctypes.data, delta.ctypes.data,
+                                   table.ctypes.data)
+    return dict(mult=mult, bias=bias, thr=thr, delta=delta, table=table)
 
 
 def version() -> str:
@@ -166,8 +178,17 @@ class Encoder:
         except Exception:
             pass
 
-    def set_profiling(self, on: bool):
-        lib.jpegamd_encoder_set_profiling(self._h, 1 if on else 0)
+    def set_profiling(self, slots: int):
+        rc = lib.jpegamd_encoder_set_profiling(self._h, int(slots))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encoder_set_profiling")
+
+    def profile(self, slot: int) -> Stats:
+        st = Stats()
+        rc = lib.jpegamd_encoder_profile(self._h, slot, C.byref(st))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encoder_profile")
+        return st
 
     @staticmethod
     def image(pixels_ptr: int, width: int, height: int, row_stride: int, bottom_up: bool = True,

@@ -1,0 +1,164 @@
+"""CPU-side checks of the product library: the C-ABI surface, host logic (BMP parsing, synthetic
+generator, constant derivation) and loud failure without a device.  No compute calls are made here."""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT, fixture_bmp, has_gpu
+
+sys.path.insert(0, str(ROOT / "tools"))
+
+
+def test_library_exports_every_declared_symbol(jpegamd):
+    header = (ROOT / "include" / "jpeg_compression.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", header))
+    declared -= {"defined"}
+    assert {"JpegCompression_Init", "convertToJpeg", "loadBMPImage", "saveJPEGGrayscale", "jpegamd_encode_async"} <= declared
+    raw = ctypes.CDLL(str(jpegamd.LIB_PATH))
+    missing = [s for s in sorted(declared) if not hasattr(raw, s)]
+    assert not missing, f"declared in include/jpeg_compression.h but not exported: {missing}"
+    assert set(jpegamd.EXPORTED) == declared
+
+
+def test_struct_layouts_match_header(jpegamd):
+    # natural_c/include/bmp_handler.h:37-41 and the DTO field order of jpeg_compression.h:32-64
+    assert ctypes.sizeof(jpegamd.BMPImage) == 16
+    assert [f[0] for f in jpegamd.DTO._fields_][:12] == ["width", "height", "r_phy_ptr", "gb_phy_ptr", "y_phy_ptr", "dct_phy_ptr",
+                                                          "quant_phy_ptr", "zigzag_phy_ptr", "rle_phy_ptr", "rle_count",
+                                                          "huff_phy_ptr", "huff_size"]
+    assert ctypes.sizeof(jpegamd.Image) == 32 and ctypes.sizeof(jpegamd.Stats) == 64
+
+
+def test_synth_generator_is_deterministic(jpegamd, manifest):
+    for e in manifest:
+        if e["source"] != "synth":
+            continue
+        bmp = fixture_bmp(e, jpegamd)
+        assert hashlib.sha256(bmp).hexdigest() == e["bmp_sha256"], e["name"]
+    b = jpegamd.synth_bmp(37, 11, 3, 0, 3)
+    assert b[:2] == b"BM" and int.from_bytes(b[10:14], "little") == 138 and int.from_bytes(b[22:26], "little", signed=True) == -11
+    assert len(b) == 138 + ((37 * 3 + 3) & ~3) * 11
+
+
+def test_parse_bmp_follows_reference_rules(jpegamd):
+    bmp = jpegamd.synth_bmp(37, 11, 3, 0, 1)
+    img, off = jpegamd.parse_bmp(bmp)
+    assert (img.width, img.height, img.row_stride, img.bottom_up, off) == (37, 11, 112, 0, 54)
+    img, off = jpegamd.parse_bmp(jpegamd.synth_bmp(8, 8, 1, 0, 2))
+    assert (img.bottom_up, off) == (1, 138)
+    bad = bytearray(bmp)
+    bad[28] = 8                                     # not 24 bpp (bmp_handler.c:44)
+    with pytest.raises(jpegamd.JpegAmdError) as ei:
+        jpegamd.parse_bmp(bytes(bad))
+    assert ei.value.code == -7
+    with pytest.raises(jpegamd.JpegAmdError):
+        jpegamd.parse_bmp(bmp[:100])                # rows missing (bmp_handler.c:104)
+    with pytest.raises(jpegamd.JpegAmdError):
+        jpegamd.parse_bmp(b"PM" + bmp[2:])          # magic (bmp_handler.c:30)
+
+
+def test_quant_constants_match_python_derivation(jpegamd):
+    import derive_guard as dg
+    for q in (50, 10, 90):
+        table = [int(x) for x in jpegamd.quant_consts(q)["table"]]
+        ref = dg.derive(table)
+        c = jpegamd.quant_consts(q)
+        assert np.allclose(c["delta"], [r["delta"] for r in ref], rtol=1e-9, atol=0)
+        assert np.allclose(c["mult"], [r["M"] for r in ref], rtol=2e-7, atol=0)
+        d = c["delta"]
+        assert np.all(c["bias"].astype(np.float64) - 0.5 >= d) and np.all(c["thr"].astype(np.float64) >= (c["bias"].astype(np.float64) - 0.5) + d)
+    t50 = jpegamd.quant_consts(50)["table"]
+    assert list(t50[:8]) == [16, 11, 10, 16, 24, 40, 51, 61] and list(jpegamd.quant_consts(0)["table"]) == list(t50)
+
+
+def test_guard_band_holds_on_float32_emulation(jpegamd, oracle):
+    """Emulate the kernel's fast path in numpy float32 (every op rounded separately: the worst case for
+    the bound) and check against the oracle: a coefficient the guard does NOT flag must already equal the
+    reference's quantised value, and the observed |z_fast - r_ref| must stay below delta_k."""
+    c = jpegamd.quant_consts(50)
+    f32 = np.float32
+    A1, A2, A4, A5 = f32(0.70710678118654752), f32(0.54119610014619698), f32(1.30656296487637653), f32(0.38268343236508977)
+
+    def aan8(d):
+        t0, t7, t1, t6 = d[0] + d[7], d[0] - d[7], d[1] + d[6], d[1] - d[6]
+        t2, t5, t3, t4 = d[2] + d[5], d[2] - d[5], d[3] + d[4], d[3] - d[4]
+        e0, e3, e1, e2 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
+        z1 = (e2 + e3) * A1
+        o0, o1, o2 = t4 + t5, t5 + t6, t6 + t7
+        z5 = (o0 - o2) * A5
+        z2, z4, z3 = o0 * A2 + z5, o2 * A4 + z5, o1 * A1
+        z11, z13 = t7 + z3, t7 - z3
+        return [e0 + e1, z11 + z4, e3 + z1, z13 - z2, e0 - e1, z13 + z2, e3 - z1, z11 - z4]
+
+    checked = flagged = 0
+    worst = 0.0
+    for (w, h, seed, kind) in [(256, 256, 3, 0), (256, 128, 9, 1), (128, 128, 101, 2), (192, 64, 0, 3)]:
+        st = oracle.stages(jpegamd.synth_bmp(w, h, seed, kind, 0))
+        ph, pw = st["y"].shape
+        blk = lambda a: a.reshape(ph // 8, 8, pw // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 8, 8)
+        y, q, dref = blk(st["y"]).astype(f32), blk(st["quant"]).astype(np.int64), blk(st["dct"]).astype(np.float64)
+        d = np.stack(aan8([y[:, :, i] for i in range(8)]), axis=2)
+        d = np.stack(aan8([d[:, i, :] for i in range(8)]), axis=1)
+        mult, bias, thr = (c[k].reshape(8, 8) for k in ("mult", "bias", "thr"))
+        zc = (d * mult + bias).astype(f32)
+        fl = np.floor(zc)
+        flag = (zc - fl) <= thr
+        flag[:, 0, 0] = True                           # DC always takes the exact integer path
+        assert np.array_equal(fl.astype(np.int64)[~flag], q[~flag])
+        err = np.abs(d.astype(np.float64) * mult.astype(np.float64) - dref / c["table"].reshape(8, 8)) / c["delta"].reshape(8, 8)
+        err[:, 0, 0] = 0
+        worst = max(worst, float(err.max()))
+        checked += flag.size
+        flagged += int(flag.sum()) - flag.shape[0]
+    assert worst < 1.0, f"observed fast-path error reached {worst:.3f} of the rigorous bound"
+    assert flagged < 0.002 * checked               # the exact path stays rare (~0.01-0.04 % here)
+
+
+def test_max_jfif_bytes_bounds_the_worst_case(jpegamd):
+    assert jpegamd.max_jfif_bytes(8, 8) >= 328 + 2 + 2 * 216
+    assert jpegamd.max_jfif_bytes(8192, 8192) > 2 * 1048576 * 215
+    assert jpegamd.max_jfif_bytes(0, 5) == 0
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device failure mode")
+def test_compute_fails_loudly_without_device(jpegamd, tmp_path):
+    bmp = jpegamd.synth_bmp(16, 16, 1, 0, 0)
+    with pytest.raises(jpegamd.JpegAmdError) as ei:
+        jpegamd.encode_bmp_bytes(bmp)
+    assert ei.value.code == -2                       # JPEGAMD_ERR_NO_DEVICE: there is no CPU fallback
+    with pytest.raises(jpegamd.JpegAmdError):
+        jpegamd.Encoder(64, 64)
+    assert jpegamd.lib.JpegCompression_Init() == -2
+    dto = jpegamd.DTO()
+    assert jpegamd.lib.convertToJpeg(ctypes.byref(dto)) == -4     # not initialised
+
+
+def test_cli_argv_contract(tmp_path):
+    app = PKG / "jpeg_compression_app"
+    r = subprocess.run([str(app)], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stderr and "<input_file_path> <output_file_path>" in r.stderr   # main.c:9-12
+    r = subprocess.run([str(app), str(tmp_path / "missing.bmp"), str(tmp_path / "o.jpg")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unable to open file" in r.stderr and "Failed to load image" in r.stderr         # main.c:29-31
+
+
+def test_load_bmp_image_matches_reference_layout(jpegamd, tmp_path):
+    bmp = jpegamd.synth_bmp(13, 7, 5, 0, 0)
+    p = tmp_path / "a.bmp"
+    p.write_bytes(bmp)
+    img = jpegamd.lib.loadBMPImage(str(p).encode())
+    assert img and (img.contents.width, img.contents.height) == (13, 7)
+    data = np.ctypeslib.as_array(img.contents.data, shape=(7, 13, 3)).copy()
+    stride = (13 * 3 + 3) & ~3
+    px = np.frombuffer(bmp, np.uint8, offset=54).reshape(7, stride)[:, :39].reshape(7, 13, 3)
+    assert np.array_equal(data, px[::-1, :, ::-1])   # flipped to top-down, BGR -> RGB (bmp_handler.c:109-122)
+    jpegamd.lib.freeBMPImage(img)
+    assert not jpegamd.lib.loadBMPImage(str(tmp_path / "nope.bmp").encode())

@@ -1,0 +1,84 @@
+"""The N > 1 path on CPU: two gloo ranks shard independent images and gather the finished
+bitstreams at rank 0 with the same StreamGather bench.py uses over RCCL.  The encoder itself
+needs a GPU, so the per-rank "encode" here is the oracle (a checker standing in for the device);
+what is under test is the sharding arithmetic and the padded gather."""
+from __future__ import annotations
+
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank: int, world: int, port: int, n_images: int, ret):
+    for p in (str(PKG / "python"), str(ROOT)):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import jpegamd
+    from jpegamd.sharding import StreamGather, owner_of, shard_range
+    from oracle import oracle
+    begin, end = shard_range(n_images, world, rank)
+    cap = 4096
+    gather = StreamGather(cap, torch.device("cpu"), dst=0, depth=2)
+    collected = {}
+    steps = max(shard_range(n_images, world, r)[1] - shard_range(n_images, world, r)[0] for r in range(world))
+    handles = []
+    for s in range(steps):
+        payload = torch.zeros(cap, dtype=torch.uint8)
+        size = torch.zeros(1, dtype=torch.int64)
+        if begin + s < end:
+            jf = oracle.encode_bmp(jpegamd.synth_bmp(24 + begin + s, 16, 50 + begin + s, 0, 0))
+            payload[:len(jf)] = torch.frombuffer(bytearray(jf), dtype=torch.uint8)
+            size[0] = len(jf)
+        h = gather.start(payload, size, s)
+        h.wait()
+        if rank == 0:
+            for r, stream in enumerate(gather.result(s)):
+                b, e = shard_range(n_images, world, r)
+                if b + s < e:
+                    collected[b + s] = stream
+                    assert owner_of(b + s, n_images, world) == r
+    if rank == 0:
+        ok = sorted(collected) == list(range(n_images))
+        for i, stream in collected.items():
+            ok &= stream == oracle.encode_bmp(jpegamd.synth_bmp(24 + i, 16, 50 + i, 0, 0))
+        ret["ok"] = bool(ok)
+        ret["n"] = len(collected)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    sys.path.insert(0, str(PKG / "python"))
+    from jpegamd.sharding import shard_range
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_gather_of_bitstreams():
+    world, n_images = 2, 5
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_images, ret), nprocs=world, join=True)
+    assert ret.get("ok") is True and ret.get("n") == n_images
