@@ -84,10 +84,11 @@ __device__ __forceinline__ int luma_clamped(const ImageDesc &im, int x, int y) {
     return (int)(((w & 0xFF) * p[0] + ((w >> 8) & 0xFF) * p[1] + ((w >> 16) & 0xFF) * p[2]) >> 8);
 }
 
-// (float) of byte 1.  Written so that hipcc selects v_cvt_f32_ubyte1 itself: an inline-asm
-// consumer right behind v_dot4 is not covered by the compiler's DOT->VALU hazard padding on
-// gfx950 and read a stale register (seen as corrupt luma on hardware).
-__device__ __forceinline__ float ubyte1_f32(uint32_t x) { return (float)(uint8_t)(x >> 8); }
+// Luma = bits 15:8 of the dot product (the sum is < 2^16).  Shift + convert: the one-instruction
+// v_cvt_f32_ubyte1 form costs ~40 more live VGPRs in hipcc's schedule (197 vs 160, one wave per
+// SIMD less), and as inline asm right behind v_dot4 it reads a stale register on gfx950 (the
+// compiler's DOT->VALU hazard padding does not cover asm operands).
+__device__ __forceinline__ float ubyte1_f32(uint32_t x) { return (float)(int)(x >> 8); }
 
 // 8 pixels (24 bytes, 4-byte aligned) -> 8 luma values via v_dot4_u32_u8.  The dot product is
 // 256*Y + fraction (< 2^16), so Y = byte 1 of the result: v_cvt_f32_ubyte1 converts it in one op.
@@ -246,11 +247,15 @@ __device__ __forceinline__ int cvt_floor_i32(float x) {
 // kStd: constants of the reference's own table baked in as instruction literals (no scalar
 // loads in the 63 quantisation sites); otherwise they come from the kernel argument block.
 #ifndef JPEGAMD_WAVES_PER_EU
-#define JPEGAMD_WAVES_PER_EU 3
+#define JPEGAMD_WAVES_PER_EU 0
+#endif
+#if JPEGAMD_WAVES_PER_EU > 0
+#define JPEGAMD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(JPEGAMD_WAVES_PER_EU, JPEGAMD_WAVES_PER_EU)))
+#else
+#define JPEGAMD_OCCUPANCY
 #endif
 template <bool kTaps, bool kStd>
-__global__ __launch_bounds__(64 * kWavesPerGroup) __attribute__((amdgpu_waves_per_eu(JPEGAMD_WAVES_PER_EU, JPEGAMD_WAVES_PER_EU)))
-void k_transform(const ImageDesc im, const QuantConsts qc,
+__global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_transform(const ImageDesc im, const QuantConsts qc,
                                                                    const TransformOut out) {
     __shared__ uint32_t s_ac[256];
     __shared__ uint32_t s_dc[16];
