@@ -41,6 +41,11 @@ struct JpegAmdEncoder {
     // cached constants
     int cur_quality = -1;
     bool std_kernel = false;     // table == reference's and baked literals == derived constants
+    int entropy_backend = 1;     // 1 = symbol-parallel (default), 0 = per-lane loop (JPEGAMD_ENTROPY=lane)
+    bool use_mfma = true;        // matrix-pipe transform kernel (JPEGAMD_KERNEL=aan|generic selects the register AAN kernel)
+    bool force_generic = false;  // JPEGAMD_KERNEL=generic: AAN kernel with run-time constants even for the reference table
+    MfmaTables *tables_dev = nullptr;
+    unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-segment phase cycle sums
     uint8_t qtable[64];
     QuantConsts qc;
     int prefix_w = -1, prefix_h = -1, prefix_q = -1;
@@ -56,9 +61,9 @@ struct JpegAmdEncoder {
     bool timed = false;
 };
 
-static int segs_for(int w, int h, int *bw, int *bh, int *spr) {
+static int segs_for(int w, int h, int *bw, int *bh, int *spr, int seg_blocks = kSegBlocks) {
     const int blocks_w = (w + 7) / 8, blocks_h = (h + 7) / 8;
-    const int per_row = (blocks_w + kSegBlocks - 1) / kSegBlocks;
+    const int per_row = (blocks_w + seg_blocks - 1) / seg_blocks;
     if (bw) *bw = blocks_w;
     if (bh) *bh = blocks_h;
     if (spr) *spr = per_row;
@@ -98,7 +103,10 @@ static void free_scratch(JpegAmdEncoder *e) {
 
 static int32_t alloc_scratch(JpegAmdEncoder *e, int max_w, int max_h) {
     const int segs = segs_for(max_w, max_h, nullptr, nullptr, nullptr);
-    HIP_TRY(hipMalloc((void **)&e->seg_words, (size_t)segs * kSegCapWords * sizeof(uint32_t)));
+    const int segs_m = segs_for(max_w, max_h, nullptr, nullptr, nullptr, kSegBlocksM);
+    size_t seg_words = (size_t)segs * kSegCapWords;
+    if ((size_t)segs_m * kSegCapWordsM > seg_words) seg_words = (size_t)segs_m * kSegCapWordsM;
+    HIP_TRY(hipMalloc((void **)&e->seg_words, seg_words * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->ovf_words, (size_t)segs * kOvfWords * 64 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->seg_bits, (size_t)segs * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->seg_syms, (size_t)segs * sizeof(uint32_t)));
@@ -126,7 +134,18 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY(hipMalloc((void **)&e->huff, 272 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->prefix, 512));
     HIP_TRY(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
+    HIP_TRY(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
+    if (std::getenv("JPEGAMD_STAMPS")) {
+        HIP_TRY(hipMalloc((void **)&e->stamps_dev, (size_t)e->max_segs * 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(e->stamps_dev, 0, (size_t)e->max_segs * 16 * sizeof(unsigned long long)));
+    }
     std::memset(&e->mirror, 0, sizeof(e->mirror));
+    // Kernel selection is fixed per context (development / A-B switches; defaults are the fast paths).
+    if (const char *force = std::getenv("JPEGAMD_KERNEL")) {
+        e->force_generic = std::strcmp(force, "generic") == 0;
+        e->use_mfma = !(e->force_generic || std::strcmp(force, "aan") == 0);
+    }
+    if (const char *ent = std::getenv("JPEGAMD_ENTROPY")) e->entropy_backend = std::strcmp(ent, "lane") == 0 ? 0 : 1;
     uint32_t words[272];
     build_huffman_words(words);
     HIP_TRY(hipMemcpy(e->huff, words, sizeof(words), hipMemcpyHostToDevice));
@@ -138,7 +157,7 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (!e) return JPEGAMD_OK;
     if (e->pending) hipStreamSynchronize(e->last_stream);
     free_scratch(e);
-    hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev);
+    hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e;
     return JPEGAMD_OK;
@@ -178,8 +197,13 @@ static int32_t prepare_constants(JpegAmdEncoder *e, const JpegAmdImage *img, boo
     if (q != e->cur_quality) {
         quant_table_for_quality(q, e->qtable);
         derive_quant_consts(e->qtable, &e->qc, nullptr);
-        const char *force = std::getenv("JPEGAMD_KERNEL");     // "generic" forces the runtime-constant kernel
-        e->std_kernel = std_consts_match_baked(e->qtable) && !(force && std::strcmp(force, "generic") == 0);
+        e->std_kernel = std_consts_match_baked(e->qtable) && !e->force_generic;
+        if (e->use_mfma) {
+            static MfmaTables host_tables;                       // 25 KiB: keep it off the stack
+            derive_mfma_tables(e->qtable, &host_tables, nullptr);
+            if (e->pending) HIP_TRY(hipStreamSynchronize(e->last_stream));
+            HIP_TRY(hipMemcpy(e->tables_dev, &host_tables, sizeof(MfmaTables), hipMemcpyHostToDevice));
+        }
         e->cur_quality = q;
     }
     if (need_prefix && (e->prefix_w != img->width || e->prefix_h != img->height || e->prefix_q != q)) {
@@ -203,11 +227,15 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     // Y = (77 R + 150 G + 29 B) >> 8 (natural_c/src/core/converter.c:51); weights follow the STORED byte order.
     d->weights = img->channel_order == JPEGAMD_ORDER_BGR ? (29u | (150u << 8) | (77u << 16))
                                                          : (77u | (150u << 8) | (29u << 16));
-    d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row);
+    d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row,
+                           (e && e->use_mfma) ? kSegBlocksM : kSegBlocks);
     d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0) ? 1 : 0;
     if (e && d->num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
     return JPEGAMD_OK;
 }
+
+static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
+                                void *stream);
 
 static TransformOut transform_out(const JpegAmdEncoder *e) {
     TransformOut t;
@@ -215,6 +243,21 @@ static TransformOut transform_out(const JpegAmdEncoder *e) {
     t.seg_words = e->seg_words; t.seg_bits = e->seg_bits; t.seg_syms = e->seg_syms; t.seg_exact = e->seg_exact;
     t.ovf_words = e->ovf_words; t.huff = e->huff;
     return t;
+}
+
+static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
+                                void *stream) {
+    if (e->use_mfma) {
+        TransformOutM to;
+        std::memset(&to, 0, sizeof(to));
+        to.seg_words = e->seg_words; to.seg_bits = e->seg_bits; to.seg_syms = e->seg_syms; to.seg_exact = e->seg_exact;
+        to.huff = e->huff; to.tables = e->tables_dev; to.stamps = e->stamps_dev;
+        to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
+        return launch_transform_mfma(im, to, taps, stream);
+    }
+    TransformOut to = transform_out(e);
+    to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
+    return launch_transform(im, e->qc, to, taps, e->std_kernel, e->entropy_backend, stream);
 }
 
 extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *img, void *out_dev,
@@ -236,14 +279,14 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         ++e->calls;
         HIP_TRY(hipEventRecord(ev[0], stream));
     }
-    TransformOut to = transform_out(e);
-    if (launch_transform(im, e->qc, to, false, e->std_kernel, stream)) return JPEGAMD_ERR_HIP;
+    if (launch_any_transform(e, im, false, nullptr, nullptr, nullptr, stream)) return JPEGAMD_ERR_HIP;
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
     if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
         return JPEGAMD_ERR_HIP;
 
     PackArgs pa;
     std::memset(&pa, 0, sizeof(pa));
+    pa.seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
     pa.seg_words = e->seg_words; pa.seg_bits = e->seg_bits; pa.seg_bitstart = e->seg_bitstart;
     pa.seg_ff = e->seg_ff; pa.seg_ffstart = e->seg_ffstart; pa.num_segs = im.num_segs;
     pa.out = (uint8_t *)out_dev; pa.out_capacity = out_capacity; pa.out_size = out_size_dev; pa.stats = e->stats_dev;
@@ -292,10 +335,17 @@ extern "C" int32_t jpegamd_debug_stages(JpegAmdEncoder *e, const JpegAmdImage *i
     if (rc) return rc;
     rc = prepare_constants(e, img, false);
     if (rc) return rc;
-    TransformOut to = transform_out(e);
-    to.tap_y = y_centered; to.tap_zz = quant_zigzag; to.tap_mask = exact_mask;
-    if (launch_transform(im, e->qc, to, true, e->std_kernel, nullptr)) return JPEGAMD_ERR_HIP;
+    if (launch_any_transform(e, im, true, y_centered, quant_zigzag, exact_mask, nullptr)) return JPEGAMD_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(nullptr));
+    return JPEGAMD_OK;
+}
+
+// Diagnostic: copy the per-segment phase cycle sums of the last launch (null unless JPEGAMD_STAMPS is set
+// in the environment AND the library was built with -DJPEGAMD_STAMPS).  Not part of the public header.
+extern "C" int32_t jpegamd_debug_read_stamps(JpegAmdEncoder *e, unsigned long long *host, int64_t nsegs) {
+    if (!e || !e->stamps_dev || !host || nsegs > e->max_segs) return JPEGAMD_ERR_ARG;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host, e->stamps_dev, (size_t)nsegs * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return JPEGAMD_OK;
 }
 
@@ -365,18 +415,16 @@ namespace jpegamd {
 // Block (0,0) through the stage taps: centred luma, exact-order DCT, quantised zigzag.
 int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64], float dct[64], int16_t zz[64]) {
     ImageDesc im;
-    int32_t rc = describe(nullptr, img, &im);
+    int32_t rc = prepare_constants(e, img, false);
     if (rc) return rc;
-    rc = prepare_constants(e, img, false);
+    rc = describe(e, img, &im);
     if (rc) return rc;
     im.blocks_w = 1; im.blocks_h = 1; im.segs_per_row = 1; im.num_segs = 1;   // block (0,0) only
     int8_t *y_dev = nullptr; int16_t *zz_dev = nullptr; float *dct_dev = nullptr;
     HIP_TRY(hipMalloc((void **)&y_dev, 64));
     HIP_TRY(hipMalloc((void **)&zz_dev, 128));
     HIP_TRY(hipMalloc((void **)&dct_dev, 256));
-    TransformOut to = transform_out(e);
-    to.tap_y = y_dev; to.tap_zz = zz_dev;
-    int err = launch_transform(im, e->qc, to, true, e->std_kernel, nullptr);
+    int err = launch_any_transform(e, im, true, y_dev, zz_dev, nullptr, nullptr);
     if (!err) err = launch_dct_exact(y_dev, dct_dev, 1, nullptr);
     if (!err) err = (int)hipMemcpy(y, y_dev, 64, hipMemcpyDeviceToHost);
     if (!err) err = (int)hipMemcpy(zz, zz_dev, 128, hipMemcpyDeviceToHost);

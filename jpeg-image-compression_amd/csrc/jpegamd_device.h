@@ -1,0 +1,154 @@
+// jpegamd_device.h -- device-side helpers shared by the transform kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jpegamd_internal.h"
+
+namespace jpegamd {
+
+// ------------------------------------------------------------------------------------
+// Tables
+// ------------------------------------------------------------------------------------
+
+// zigzag position -> raster index (zigzag.c:7-15)
+__device__ constexpr uint8_t kZZ[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// The reference's cosine LUT (dct.c:9-18) stored frequency-major: kCosFM[u*8+x] = COS_LUT[x][u].
+static __constant__ float kCosFM[64] = {
+    1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f,
+    0.980785f, 0.831470f, 0.555570f, 0.195090f, -0.195090f, -0.555570f, -0.831470f, -0.980785f,
+    0.923880f, 0.382683f, -0.382683f, -0.923880f, -0.923880f, -0.382684f, 0.382684f, 0.923880f,
+    0.831470f, -0.195090f, -0.980785f, -0.555570f, 0.555570f, 0.980785f, 0.195091f, -0.831470f,
+    0.707107f, -0.707107f, -0.707107f, 0.707107f, 0.707107f, -0.707107f, -0.707107f, 0.707107f,
+    0.555570f, -0.980785f, 0.195090f, 0.831470f, -0.831470f, -0.195090f, 0.980785f, -0.555570f,
+    0.382683f, -0.923880f, 0.923880f, -0.382683f, -0.382684f, 0.923880f, -0.923879f, 0.382684f,
+    0.195090f, -0.555570f, 0.831470f, -0.980785f, 0.980785f, -0.831470f, 0.555570f, -0.195090f};
+
+// 0.25f * C(u) * C(v), left-associated float32 products (dct.c:87-93).
+__device__ __forceinline__ float ref_scale(int u, int v) {
+    const float cu = (u == 0) ? 0.707107f : 1.000000f;
+    const float cv = (v == 0) ? 0.707107f : 1.000000f;
+    return __fmul_rn(__fmul_rn(0.25f, cu), cv);
+}
+
+// quantization.c:34-36: float32 division, roundf (half away from zero).
+__device__ __forceinline__ int ref_quantise(float coef, float qstep) {
+    return (int)roundf(__fdiv_rn(coef, qstep));
+}
+
+// ------------------------------------------------------------------------------------
+// Pixel access
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ const uint8_t *row_ptr(const ImageDesc &im, int y) {
+    const int stored = im.bottom_up ? (im.height - 1 - y) : y;      // bmp_handler.c:109
+    return im.pixels + (size_t)stored * (size_t)im.row_stride;
+}
+
+// Luma of image pixel (x, y) with the converter's edge clamp (converter.c:31,36,51).
+__device__ __forceinline__ int luma_clamped(const ImageDesc &im, int x, int y) {
+    x = min(x, im.width - 1);
+    y = min(y, im.height - 1);
+    const uint8_t *p = row_ptr(im, y) + 3 * (size_t)x;
+    const uint32_t w = im.weights;
+    return (int)(((w & 0xFF) * p[0] + ((w >> 8) & 0xFF) * p[1] + ((w >> 16) & 0xFF) * p[2]) >> 8);
+}
+
+// Luma = bits 15:8 of the dot product (the sum is < 2^16).  Shift + convert: the one-instruction
+// v_cvt_f32_ubyte1 form costs ~40 more live VGPRs in hipcc's schedule (197 vs 160, one wave per
+// SIMD less), and as inline asm right behind v_dot4 it reads a stale register on gfx950 (the
+// compiler's DOT->VALU hazard padding does not cover asm operands).
+__device__ __forceinline__ float ubyte1_f32(uint32_t x) { return (float)(int)(x >> 8); }
+
+// 8 pixels (24 bytes, 4-byte aligned) -> 8 luma values via v_dot4_u32_u8.  The dot product is
+// 256*Y + fraction (< 2^16), so Y = byte 1 of the result: v_cvt_f32_ubyte1 converts it in one op.
+__device__ __forceinline__ void luma_row8(const uint32_t *__restrict__ src, uint32_t w, float *y) {
+    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4], d5 = src[5];
+    const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu;
+    const uint32_t wA = w;                         // pixel in bytes 0..2
+    const uint32_t wB0 = c0 << 24, wB1 = c1 | (c2 << 8);          // byte 3 | bytes 0..1
+    const uint32_t wC0 = (c0 << 16) | (c1 << 24), wC1 = c2;       // bytes 2..3 | byte 0
+    const uint32_t wD = w << 8;                    // pixel in bytes 1..3
+    y[0] = ubyte1_f32(__builtin_amdgcn_udot4(d0, wA, 0u, false));
+    y[1] = ubyte1_f32(__builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, 0u, false), false));
+    y[2] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, 0u, false), false));
+    y[3] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wD, 0u, false));
+    y[4] = ubyte1_f32(__builtin_amdgcn_udot4(d3, wA, 0u, false));
+    y[5] = ubyte1_f32(__builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, 0u, false), false));
+    y[6] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, 0u, false), false));
+    y[7] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wD, 0u, false));
+}
+
+// ------------------------------------------------------------------------------------
+// Wave helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// Cross-lane helpers on DPP / v_readlane (no LDS crossbar round trips: __shfl_* compiles to
+// ds_bpermute_b32, ~100+ cycles per step on the critical path of a wave).
+template <int kCtrl, int kRowMask = 0xF>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {        // lanes without a source (or masked rows) read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xF, false);
+}
+// inclusive prefix sum inside each 32-lane half (rows of 16: row_shr 1,2,4,8, then row_bcast:15 into rows 1 and 3)
+__device__ __forceinline__ uint32_t half_incl_scan_dpp(uint32_t v) {
+    v += dpp_or_zero<0x111>(v);
+    v += dpp_or_zero<0x112>(v);
+    v += dpp_or_zero<0x114>(v);
+    v += dpp_or_zero<0x118>(v);
+    v += dpp_or_zero<0x142, 0xA>(v);
+    return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/ = 0) {
+    v = half_incl_scan_dpp(v);
+    v += dpp_or_zero<0x143, 0xC>(v);                                  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    return __builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)v), 63);
+}
+// value of lane - 1 (lane 0 reads 0): wave_shr:1
+__device__ __forceinline__ int lane_shift_up1(int v) { return (int)dpp_or_zero<0x138>((uint32_t)v); }
+// value of lane ^ 32 (v_permlane32_swap)
+__device__ __forceinline__ uint32_t other_half(uint32_t v, int lane) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return lane < 32 ? r[1] : r[0];
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ------------------------------------------------------------------------------------
+// Exact-order coefficient (dct.c:72-93 + quantization.c:34-36), cooperative: lane j owns
+// term j = x*8+y of block (bx, by); the ordered float32 sum s_j = fl(s_{j-1} + t_j) is a
+// 63-step DPP wave_shr chain.  Must be called with all 64 lanes active; (bx, by, u, v)
+// wave-uniform.  Returns the quantised value in every lane.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float exact_term_sum(float t) {
+    // After step i every lane j <= i holds fl(...fl(t_0 + t_1)... + t_j).
+    float acc = t;
+#pragma unroll 1
+    for (int i = 1; i < 64; ++i) {
+        const float prev = __builtin_bit_cast(
+            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x138 /*wave_shr:1*/, 0xF,
+                                               0xF, false));
+        // lane 0 receives 0.0f: fl(t_0 + 0) == t_0, so lane 0 stays t_0 (dct.c:68 starts at 0.0f).
+        acc = __fadd_rn(t, prev);
+    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+}
+
+__device__ __forceinline__ float exact_coef_float(float pixel /*lane j: p[x=j>>3][y=j&7]*/, int u, int v,
+                                                  const float *s_cos, int lane) {
+    const float cx = s_cos[u * 8 + (lane >> 3)];     // COS_LUT[x][u]
+    const float cy = s_cos[v * 8 + (lane & 7)];      // COS_LUT[y][v]
+    const float t = __fmul_rn(__fmul_rn(pixel, cx), cy);             // dct.c:84
+    const float s = exact_term_sum(t);
+    return __fmul_rn(ref_scale(u, v), s);                            // dct.c:93
+}
+
+}  // namespace jpegamd

@@ -38,6 +38,25 @@ struct StdConsts {
     float bias;        // 0.5 + max_k delta_k
 };
 
+// ---- matrix-pipe transform (jpegamd_transform_mfma.hip) ---------------------------------
+// A "tile" is 32 consecutive blocks of one block row, one v_mfma_f32_32x32x16_bf16 column
+// each; lane l = (h = l >> 5, b = l & 31) ends up with 32 coefficients of block b: zigzag
+// positions 32h + 16H + r for chain H in {0,1}, accumulator register r in [0,16).
+constexpr int kTileBlocks = 32;
+constexpr int kSegTiles = 4;                         // tiles per segment (= per wavefront)
+constexpr int kSegBlocksM = kTileBlocks * kSegTiles; // 128
+constexpr int kSegCapWordsM = ((kSegBlocksM * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64;
+constexpr int kAFragWords = 3 * 2 * 4 * 64 * 4;      // [term][chain][kstep][lane] x 8 bf16 = 24 KiB
+
+struct MfmaTables {
+    uint32_t afrag[kAFragWords];   // LUT-product matrix, 3-way bf16 split (lo, mid, hi), MFMA A-operand order
+    float qmul[64];                // by zigzag position z: M_z = K/(q)  (the MFMA output is the plain LUT sum)
+    float qthr[64];                // (bias - 0.5) + delta_z
+    float qstep[64];               // (float) q, by zigzag position
+    float bias;                    // 0.5 + max_z delta_z
+    float pad[3];
+};
+
 struct ImageDesc {
     const uint8_t *pixels;
     int32_t width, height, row_stride, bottom_up;
@@ -71,6 +90,7 @@ struct ScanStats {                   // device-side per-call record (scan kernel
 
 struct PackArgs {
     const uint32_t *seg_words;
+    uint32_t seg_stride;            // words reserved per segment (kSegCapWords or kSegCapWordsM)
     const uint32_t *seg_bits;
     const uint64_t *seg_bitstart;   // [num_segs+1]
     uint32_t *seg_ff;               // [num_segs] (count kernel output)
@@ -89,19 +109,31 @@ struct PackArgs {
 // ---- launchers (jpegamd_kernels.hip) ---------------------------------------------------
 // All take a hipStream_t as void* and return a hipError_t as int.
 int launch_transform(const ImageDesc &im, const QuantConsts &qc, const TransformOut &out,
-                     bool taps, bool std_table, void *stream);
+                     bool taps, bool std_table, int entropy_backend, void *stream);
 int launch_scan_bits(const uint32_t *seg_bits, const uint32_t *seg_syms, const uint32_t *seg_exact,
                      uint64_t *seg_bitstart, int num_segs, ScanStats *stats, void *stream);
 int launch_count_ff(const PackArgs &a, void *stream);
 int launch_scan_ff(const uint32_t *seg_ff, uint64_t *seg_ffstart, int num_segs, ScanStats *stats,
                    void *stream);
 int launch_pack(const PackArgs &a, void *stream);
+struct TransformOutM {          // like TransformOut, for the matrix-pipe kernel (segments of 128 blocks)
+    uint32_t *seg_words;        // [num_segs][kSegCapWordsM]
+    uint32_t *seg_bits, *seg_syms, *seg_exact;
+    const uint32_t *huff;       // [272]
+    const MfmaTables *tables;   // device copy
+    unsigned long long *stamps; // [num_segs][16] per-phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
+    int8_t *tap_y;
+    int16_t *tap_zz;
+    uint64_t *tap_mask;
+};
+int launch_transform_mfma(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream);
 int launch_dct_exact(const int8_t *blocks, float *coeffs, int64_t nblocks, void *stream);
 
 // ---- host-side constant derivation (quant_consts.cpp) ----------------------------------
 void quant_table_for_quality(int quality, uint8_t table[64]);
 void derive_quant_consts(const uint8_t table[64], QuantConsts *qc, double delta_out[64]);
 void derive_std_consts(const uint8_t table[64], StdConsts *sc);
+void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64] /*by raster k, may be null*/);
 bool std_consts_match_baked(const uint8_t table[64]);   // table is the reference's AND baked == derived
 void build_huffman_words(uint32_t words[272]);
 size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]);

@@ -28,11 +28,89 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "jpegamd_device.h"
+#include "jpegamd_internal.h"
 
+#ifndef JPEGAMD_ABLATE
+#define JPEGAMD_ABLATE 0
+#endif
 namespace jpegamd {
 
 #include "std_table_consts.inc"
+
+// ------------------------------------------------------------------------------------
+// Tables
+// ------------------------------------------------------------------------------------
+
+// zigzag position -> raster index (zigzag.c:7-15)
+__device__ constexpr uint8_t kZZ[64] = {
+    0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// The reference's cosine LUT (dct.c:9-18) stored frequency-major: kCosFM[u*8+x] = COS_LUT[x][u].
+__constant__ float kCosFM[64] = {
+    1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f, 1.000000f,
+    0.980785f, 0.831470f, 0.555570f, 0.195090f, -0.195090f, -0.555570f, -0.831470f, -0.980785f,
+    0.923880f, 0.382683f, -0.382683f, -0.923880f, -0.923880f, -0.382684f, 0.382684f, 0.923880f,
+    0.831470f, -0.195090f, -0.980785f, -0.555570f, 0.555570f, 0.980785f, 0.195091f, -0.831470f,
+    0.707107f, -0.707107f, -0.707107f, 0.707107f, 0.707107f, -0.707107f, -0.707107f, 0.707107f,
+    0.555570f, -0.980785f, 0.195090f, 0.831470f, -0.831470f, -0.195090f, 0.980785f, -0.555570f,
+    0.382683f, -0.923880f, 0.923880f, -0.382683f, -0.382684f, 0.923880f, -0.923879f, 0.382684f,
+    0.195090f, -0.555570f, 0.831470f, -0.980785f, 0.980785f, -0.831470f, 0.555570f, -0.195090f};
+
+// 0.25f * C(u) * C(v), left-associated float32 products (dct.c:87-93).
+__device__ __forceinline__ float ref_scale(int u, int v) {
+    const float cu = (u == 0) ? 0.707107f : 1.000000f;
+    const float cv = (v == 0) ? 0.707107f : 1.000000f;
+    return __fmul_rn(__fmul_rn(0.25f, cu), cv);
+}
+
+// quantization.c:34-36: float32 division, roundf (half away from zero).
+__device__ __forceinline__ int ref_quantise(float coef, float qstep) {
+    return (int)roundf(__fdiv_rn(coef, qstep));
+}
+
+// ------------------------------------------------------------------------------------
+// Pixel access
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ const uint8_t *row_ptr(const ImageDesc &im, int y) {
+    const int stored = im.bottom_up ? (im.height - 1 - y) : y;      // bmp_handler.c:109
+    return im.pixels + (size_t)stored * (size_t)im.row_stride;
+}
+
+// Luma of image pixel (x, y) with the converter's edge clamp (converter.c:31,36,51).
+__device__ __forceinline__ int luma_clamped(const ImageDesc &im, int x, int y) {
+    x = min(x, im.width - 1);
+    y = min(y, im.height - 1);
+    const uint8_t *p = row_ptr(im, y) + 3 * (size_t)x;
+    const uint32_t w = im.weights;
+    return (int)(((w & 0xFF) * p[0] + ((w >> 8) & 0xFF) * p[1] + ((w >> 16) & 0xFF) * p[2]) >> 8);
+}
+
+// Luma = bits 15:8 of the dot product (the sum is < 2^16).  Shift + convert: the one-instruction
+// v_cvt_f32_ubyte1 form costs ~40 more live VGPRs in hipcc's schedule (197 vs 160, one wave per
+// SIMD less), and as inline asm right behind v_dot4 it reads a stale register on gfx950 (the
+// compiler's DOT->VALU hazard padding does not cover asm operands).
+__device__ __forceinline__ float ubyte1_f32(uint32_t x) { return (float)(int)(x >> 8); }
+
+// 8 pixels (24 bytes, 4-byte aligned) -> 8 luma values via v_dot4_u32_u8.  The dot product is
+// 256*Y + fraction (< 2^16), so Y = byte 1 of the result: v_cvt_f32_ubyte1 converts it in one op.
+__device__ __forceinline__ void luma_row8(const uint32_t *__restrict__ src, uint32_t w, float *y) {
+    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4], d5 = src[5];
+    const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu;
+    const uint32_t wA = w;                         // pixel in bytes 0..2
+    const uint32_t wB0 = c0 << 24, wB1 = c1 | (c2 << 8);          // byte 3 | bytes 0..1
+    const uint32_t wC0 = (c0 << 16) | (c1 << 24), wC1 = c2;       // bytes 2..3 | byte 0
+    const uint32_t wD = w << 8;                    // pixel in bytes 1..3
+    y[0] = ubyte1_f32(__builtin_amdgcn_udot4(d0, wA, 0u, false));
+    y[1] = ubyte1_f32(__builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, 0u, false), false));
+    y[2] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, 0u, false), false));
+    y[3] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wD, 0u, false));
+    y[4] = ubyte1_f32(__builtin_amdgcn_udot4(d3, wA, 0u, false));
+    y[5] = ubyte1_f32(__builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, 0u, false), false));
+    y[6] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, 0u, false), false));
+    y[7] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wD, 0u, false));
+}
 
 // ------------------------------------------------------------------------------------
 // Fast 8-point DCT (Arai-Agui-Nakajima flow graph), in place, stride S.
@@ -66,6 +144,58 @@ __device__ __forceinline__ void aan8(float *d) {
     d[3 * S] = z13 - z2;
     d[1 * S] = z11 + z4;
     d[7 * S] = z11 - z4;
+}
+
+// ------------------------------------------------------------------------------------
+// Wave helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// inclusive prefix sum across the wave
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ------------------------------------------------------------------------------------
+// Exact-order coefficient (dct.c:72-93 + quantization.c:34-36), cooperative: lane j owns
+// term j = x*8+y of block (bx, by); the ordered float32 sum s_j = fl(s_{j-1} + t_j) is a
+// 63-step DPP wave_shr chain.  Must be called with all 64 lanes active; (bx, by, u, v)
+// wave-uniform.  Returns the quantised value in every lane.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float exact_term_sum(float t) {
+    // After step i every lane j <= i holds fl(...fl(t_0 + t_1)... + t_j).
+    float acc = t;
+#pragma unroll 1
+    for (int i = 1; i < 64; ++i) {
+        const float prev = __builtin_bit_cast(
+            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x138 /*wave_shr:1*/, 0xF,
+                                               0xF, false));
+        // lane 0 receives 0.0f: fl(t_0 + 0) == t_0, so lane 0 stays t_0 (dct.c:68 starts at 0.0f).
+        acc = __fadd_rn(t, prev);
+    }
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
+}
+
+__device__ __forceinline__ float exact_coef_float(float pixel /*lane j: p[x=j>>3][y=j&7]*/, int u, int v,
+                                                  const float *s_cos, int lane) {
+    const float cx = s_cos[u * 8 + (lane >> 3)];     // COS_LUT[x][u]
+    const float cy = s_cos[v * 8 + (lane & 7)];      // COS_LUT[y][v]
+    const float t = __fmul_rn(__fmul_rn(pixel, cx), cy);             // dct.c:84
+    const float s = exact_term_sum(t);
+    return __fmul_rn(ref_scale(u, v), s);                            // dct.c:93
 }
 
 // ------------------------------------------------------------------------------------
@@ -122,151 +252,23 @@ __device__ __forceinline__ int cvt_floor_i32(float x) {
 #ifndef JPEGAMD_WAVES_PER_EU
 #define JPEGAMD_WAVES_PER_EU 0
 #endif
-
-// ------------------------------------------------------------------------------------
-// Symbol-parallel entropy back-end.
-//
-// The per-lane loop of the first back-end keeps ~16 % of the lanes busy (a lane only works at
-// the zigzag positions where ITS block is non-zero).  Here each lane only *records* its
-// non-zeros -- (run, value) items appended to its own range of an LDS list (ranges come from
-// a wave prefix sum of per-lane counts) -- and then the wave walks the list 64 items at a
-// time with one lane per SYMBOL: size, amplitude, Huffman code and length (rle.c:9-35,99-123;
-// huffman.c:145-188), a wave prefix sum of the lengths gives every symbol its bit offset in
-// the segment, and the bits are OR-ed into a small LDS window that is flushed to the
-// segment's word array as it fills.  Items per block: DC, the non-zero ACs in zigzag order,
-// EOB when coefficient 63 is zero.  A run >= 16 becomes 1..3 ZRL prefixes on the item.
-//
-// List capacity is bounded (kItemCap); segments with more symbols are processed in groups of
-// consecutive blocks, so dense / adversarial content stays correct, only slower.
-// ------------------------------------------------------------------------------------
-constexpr int kItemCap = (kPrivWords + 1) * 64;     // 1024 items in the former private-word area
-constexpr uint32_t kItemDc = 0x80000000u;
-
-__device__ __forceinline__ uint32_t entropy_symbol_parallel(const int (&n)[64], int pred, bool active, int lane,
-                                                            WaveLds &wl, const uint32_t *s_huff /*ac[256] dc[16]*/,
-                                                            uint32_t *__restrict__ segw, int &nsym_out) {
-    uint32_t *items = wl.priv;                      // [kItemCap]
-    uint32_t *win = reinterpret_cast<uint32_t *>(wl.ev_mask);   // 128-word bit window (events are done)
-
-    // ---- per-lane symbol count and its prefix sum --------------------------------------
-    int nnz = 0;
-#pragma unroll
-    for (int i = 1; i < 64; ++i) nnz += (n[kZZ[i]] != 0) ? 1 : 0;
-    const bool eob = n[kZZ[63]] == 0;                               // rle.c:121-123
-    const uint32_t cnt = active ? (uint32_t)(1 + nnz + (eob ? 1 : 0)) : 0u;
-    const uint32_t incl = wave_incl_scan_u32(cnt, lane);
-    const uint32_t base = incl - cnt;
-    const uint32_t t_all = __shfl(incl, 63, 64);
-
-    uint32_t carry_bits = 0;          // bits emitted so far in this segment (wave-uniform)
-    uint32_t wbase = 0;               // word index of win[0] in the segment
-    int zrl_total = 0;
-    if (lane == 0) win[0] = 0u;
-
-    uint32_t gbase = 0;               // first item of the current group
-    while (gbase < t_all) {
-        // group = maximal run of consecutive lanes whose items fit the list (every block <= 65 items)
-        const bool fits = (incl - gbase) <= (uint32_t)kItemCap;
-        const bool mine = active && base >= gbase && fits;
-        const unsigned long long gm = __ballot(mine);
-        const uint32_t gend_incl = __shfl(incl, 63 - __builtin_clzll(gm), 64);   // last lane of the group
-        const uint32_t gt = gend_incl - gbase;                                   // items in this group
-
-        // ---- scatter: every lane appends its items to its own range ---------------------
-        if (mine) {
-            uint32_t ptr = base - gbase;
-            items[ptr++] = kItemDc | (uint32_t)((n[0] - pred) & 0xFFFF);         // rle.c:68-76
-            int last = 0;
-#pragma unroll
-            for (int i = 1; i < 64; ++i) {
-                const int v = n[kZZ[i]];
-                if (v != 0) {
-                    items[ptr++] = ((uint32_t)(i - last - 1) << 16) | (uint32_t)(v & 0xFFFF);
-                    last = i;
-                }
-            }
-            if (eob) items[ptr] = 0u;                                             // value 0, not DC = EOB
-        }
-
-        // ---- one lane per symbol -------------------------------------------------------
-        for (uint32_t b0 = 0; b0 < gt; b0 += 64) {
-            const uint32_t idx = b0 + (uint32_t)lane;
-            const bool valid = idx < gt;
-            const uint32_t it = valid ? items[idx] : 0u;
-            const int v = (int)(short)(it & 0xFFFFu);
-            const bool isdc = (it & kItemDc) != 0u;
-            const int run = (int)((it >> 16) & 0x7FFFu);
-            const int nb = v ? (32 - __clz(abs(v))) : 0;                          // rle.c:9-22
-            const uint32_t amp = (uint32_t)(v + (v >> 31)) & ((1u << nb) - 1u);   // rle.c:24-35
-            const uint32_t hc = s_huff[isdc ? (256 + nb) : (((run & 15) << 4) | nb)];
-            uint32_t hi = ((hc & 0xFFFFu) << nb) | amp;                           // code bits then amplitude bits
-            uint32_t lo = 0;
-            int len = valid ? (int)(hc >> 16) + nb : 0;                           // <= 27
-            const int zrl = (valid && !isdc) ? (run >> 4) : 0;                    // rle.c:99-103
-            hi <<= (32 - len) & 31;                                               // left-align (len == 0 -> hi == 0 anyway)
-            if (len == 0) hi = 0;
-            if (__builtin_expect(__any(zrl != 0), 0)) {
-                // prepend zrl x "11111111001" (huffman code of 0xF0): up to 33 + 27 bits
-                const uint32_t z = s_huff[0xF0];
-                const uint32_t zc = z & 0xFFFFu;
-                const int zl = (int)(z >> 16);
-                unsigned long long acc = ((unsigned long long)hi << 32);
-                int tot = len;
-                for (int r = 0; r < 3; ++r) {
-                    if (r < zrl) { acc = (acc >> zl) | ((unsigned long long)zc << (64 - zl)); tot += zl; }
-                }
-                hi = (uint32_t)(acc >> 32);
-                lo = (uint32_t)acc;
-                len = tot;
-                zrl_total += zrl;
-            }
-            const uint32_t incl_b = wave_incl_scan_u32((uint32_t)len, lane);
-            const uint32_t batch_bits = __shfl(incl_b, 63, 64);
-            const uint32_t rel = carry_bits + incl_b - (uint32_t)len - wbase * 32u;   // bit offset inside the window
-            // clear the part of the window this batch can reach (win[0] holds the carried partial word)
-            win[1 + lane] = 0u;
-            if (lane < 63) win[65 + lane] = 0u;
-            if (len) {
-                const uint32_t w = rel >> 5, sh = rel & 31u;
-                atomicOr(&win[w], __builtin_amdgcn_alignbit(0u, hi, sh));
-                const uint32_t w1 = __builtin_amdgcn_alignbit(hi, lo, sh);
-                if (w1) atomicOr(&win[w + 1], w1);
-                const uint32_t w2 = __builtin_amdgcn_alignbit(lo, 0u, sh);
-                if (w2) atomicOr(&win[w + 2], w2);
-            }
-            carry_bits += batch_bits;
-            const uint32_t done = (carry_bits >> 5) - wbase;        // complete words now in the window (<= 121)
-            if ((uint32_t)lane < done) segw[wbase + lane] = win[lane];
-            if ((uint32_t)lane + 64u < done) segw[wbase + 64u + lane] = win[64 + lane];
-            const uint32_t part = win[done];                        // every lane reads it before lane 0 overwrites win[0]
-            if (lane == 0) win[0] = part;
-            wbase += done;
-        }
-        gbase = gend_incl;
-    }
-    if ((carry_bits & 31u) && lane == 0) segw[wbase] = win[0];      // last partial word, zero-padded
-    nsym_out = (int)cnt + zrl_total;      // per-lane: symbols of this block (+ the ZRLs this lane coded); summed by the caller
-    return carry_bits;
-}
-
 #if JPEGAMD_WAVES_PER_EU > 0
 #define JPEGAMD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(JPEGAMD_WAVES_PER_EU, JPEGAMD_WAVES_PER_EU)))
 #else
 #define JPEGAMD_OCCUPANCY
 #endif
-template <bool kTaps, bool kStd, int kEntropy>
+template <bool kTaps, bool kStd>
 __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_transform(const ImageDesc im, const QuantConsts qc,
                                                                    const TransformOut out) {
-    __shared__ uint32_t s_huff[272];          // AC codes [0,256) then DC codes [256,272): len<<16 | code
-    uint32_t *const s_ac = s_huff;
-    uint32_t *const s_dc = s_huff + 256;
+    __shared__ uint32_t s_ac[256];
+    __shared__ uint32_t s_dc[16];
     __shared__ float s_cos[64];
     __shared__ WaveLds s_wave[kWavesPerGroup];
 
     {
         const int t = (int)threadIdx.x;
-        s_huff[t] = out.huff[t];
-        if (t < 16) s_huff[256 + t] = out.huff[256 + t];
+        s_ac[t] = out.huff[t];
+        if (t < 16) s_dc[t] = out.huff[256 + t];
         if (t < 64) s_cos[t] = kCosFM[t];
     }
     __syncthreads();
@@ -318,10 +320,12 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
     }
 
     // ---- 2. fast 2-D DCT ----------------------------------------------------------------
+#if JPEGAMD_ABLATE < 3
 #pragma unroll
     for (int r = 0; r < 8; ++r) aan8<1>(&d[r * 8]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) aan8<8>(&d[c]);
+#endif
 
     // ---- 3. quantise with guard band; record sites needing the exact order --------------
     int n[64];
@@ -398,15 +402,10 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
     int pred = __shfl_up(n[0], 1, 64);
     if (lane == 0) pred = pred_first;
 
-    uint32_t *segw = out.seg_words + (size_t)seg * kSegCapWords;
-    uint32_t total = 0;
-    int nsym = 0;
-    if constexpr (kEntropy == 1) {
-        total = entropy_symbol_parallel(n, pred, active, lane, wl, s_huff, segw, nsym);
-    } else {
     // ---- 6. run/size symbols + Huffman codes into the lane's private bit string -----------
     uint32_t *ovf = out.ovf_words + (size_t)seg * (kOvfWords * 64);
     BitAcc ba;
+    int nsym = 0;
     if (active) {
         {   // DC (rle.c:68-76, huffman.c:145-153)
             const int diff = n[0] - pred;
@@ -416,6 +415,11 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
             append_bits(ba, wl, ovf, lane, code, (int)(hc >> 16) + nb);
             ++nsym;
         }
+#if JPEGAMD_ABLATE >= 1
+        int last = 0; { int acc_ = 0;
+#pragma unroll
+        for (int i = 1; i < 64; ++i) acc_ |= n[kZZ[i]]; if (acc_ == 12345) last = 5; }
+#else
         int last = 0;
 #pragma unroll
         for (int i = 1; i < 64; ++i) {
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
                 ++nsym;
             }
         }
+#endif
         if (last != 63) {                                 // EOB (rle.c:121-123)
             const uint32_t he = s_ac[0x00];
             append_bits(ba, wl, ovf, lane, he & 0xFFFFu, (int)(he >> 16));
@@ -448,12 +453,14 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
     // ---- 7. segment assembly: scan block lengths, gather words, store ---------------------
     const uint32_t incl = wave_incl_scan_u32(my_bits, lane);
     wl.offs[lane] = incl - my_bits;
-    total = __shfl(incl, 63, 64);
+    const uint32_t total = __shfl(incl, 63, 64);
     if (lane == 0) { wl.offs[64] = total; wl.offs[65] = total; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);   // private words (LDS + HBM overflow) and offsets are visible to the wave
     __builtin_amdgcn_wave_barrier();
 
+#if JPEGAMD_ABLATE < 2
+    uint32_t *segw = out.seg_words + (size_t)seg * kSegCapWords;
     const uint32_t nwords = (total + 31u) >> 5;
 #pragma unroll 1
     for (uint32_t j = (uint32_t)lane; j < nwords; j += 64) {
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
         segw[j] = word;
     }
 
-    }
+#endif
     const int seg_syms = wave_sum_i32(nsym);
     if (lane == 0) {
         out.seg_bits[seg] = total;
@@ -491,22 +498,13 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
 }
 
 int launch_transform(const ImageDesc &im, const QuantConsts &qc, const TransformOut &out, bool taps, bool std_table,
-                     int entropy_backend, void *stream) {
+                     void *stream) {
     const dim3 grid((im.num_segs + kWavesPerGroup - 1) / kWavesPerGroup), block(64 * kWavesPerGroup);
     hipStream_t s = (hipStream_t)stream;
-#define JPEGAMD_LAUNCH(T, S, E) hipLaunchKernelGGL((k_transform<T, S, E>), grid, block, 0, s, im, qc, out)
-    if (entropy_backend == 1) {
-        if (taps && std_table) JPEGAMD_LAUNCH(true, true, 1);
-        else if (taps) JPEGAMD_LAUNCH(true, false, 1);
-        else if (std_table) JPEGAMD_LAUNCH(false, true, 1);
-        else JPEGAMD_LAUNCH(false, false, 1);
-    } else {
-        if (taps && std_table) JPEGAMD_LAUNCH(true, true, 0);
-        else if (taps) JPEGAMD_LAUNCH(true, false, 0);
-        else if (std_table) JPEGAMD_LAUNCH(false, true, 0);
-        else JPEGAMD_LAUNCH(false, false, 0);
-    }
-#undef JPEGAMD_LAUNCH
+    if (taps && std_table) hipLaunchKernelGGL((k_transform<true, true>), grid, block, 0, s, im, qc, out);
+    else if (taps) hipLaunchKernelGGL((k_transform<true, false>), grid, block, 0, s, im, qc, out);
+    else if (std_table) hipLaunchKernelGGL((k_transform<false, true>), grid, block, 0, s, im, qc, out);
+    else hipLaunchKernelGGL((k_transform<false, false>), grid, block, 0, s, im, qc, out);
     return (int)hipGetLastError();
 }
 
@@ -641,7 +639,7 @@ __device__ __forceinline__ uint32_t tail_bits_before(const PackArgs &a, int s, i
         const uint32_t tp = a.seg_bits[sp];
         const int take = min(need - got, (int)tp);
         if (take > 0) {
-            const uint32_t bits = seg_bits_at(a.seg_words + (size_t)sp * a.seg_stride, tp - (uint32_t)take, take);
+            const uint32_t bits = seg_bits_at(a.seg_words + (size_t)sp * kSegCapWords, tp - (uint32_t)take, take);
             val |= bits << got;
             got += take;
         }
@@ -660,7 +658,7 @@ struct SegView {
 
 __device__ __forceinline__ SegView seg_view(const PackArgs &a, int s) {
     SegView v;
-    v.words = a.seg_words + (size_t)s * a.seg_stride;
+    v.words = a.seg_words + (size_t)s * kSegCapWords;
     v.b0 = a.seg_bitstart[s];
     v.b1 = v.b0 + a.seg_bits[s];
     v.nown = (uint32_t)((v.b1 >> 3) - (v.b0 >> 3));

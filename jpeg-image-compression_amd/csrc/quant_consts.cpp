@@ -221,6 +221,90 @@ void derive_std_consts(const uint8_t table[64], StdConsts *sc) {
     }
 }
 
+// ---- matrix-pipe tables ----------------------------------------------------------------------
+// out_z = sum_p Kmat[c][p] * pix[p], Kmat[c][p] = COS_LUT[x][u] * COS_LUT[y][v] (exact product of the two
+// float32 literals), computed by 12 v_mfma_f32_32x32x16_bf16 per chain: Kmat = lo + mid + hi in bf16,
+// pixels (int8) exact in bf16, so every product is exact in f32 and only accumulation rounds.
+// Guard band: E_lut vanishes (the fast path evaluates the LUT sum itself); E_aan is replaced by
+//   E_mfma = 2 * 16u * sum_m (|acc before MFMA m| + S_m),   S_m = 128 * sum_{p in k-step m} |term|
+// which holds for ANY order in which the hardware adds the 16 products of one instruction to the
+// accumulator (the factor 2 covers truncating adders); plus the split residual 128*sum|Kmat - (lo+mid+hi)|.
+// tools/ubench/mfma_dct_test.hip measured the real error at < 1 % of this bound.
+namespace {
+uint16_t to_bf16(double x) {
+    float f = (float)x;
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+double from_bf16(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return (double)f;
+}
+}  // namespace
+
+void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64]) {
+    std::memset(mt, 0, sizeof(*mt));
+    QuantConsts qc;
+    double delta_aan[64];
+    derive_quant_consts(table, &qc, delta_aan);        // for K_k, e_ref reuse we recompute below
+    uint16_t *af = reinterpret_cast<uint16_t *>(mt->afrag);
+    double delta_z[64];
+    double dmax = 0;
+    for (int z = 0; z < 64; ++z) {
+        const int k = kZigzagHost[z], u = k >> 3, v = k & 7;
+        double kmat[64], term[3][64], split_res = 0;
+        for (int x = 0; x < 8; ++x)
+            for (int y = 0; y < 8; ++y) {
+                const int p = x * 8 + y;
+                kmat[p] = (double)kCosLut[x][u] * (double)kCosLut[y][v];
+                const uint16_t hi = to_bf16(kmat[p]);
+                const double r1 = kmat[p] - from_bf16(hi);
+                const uint16_t mid = to_bf16(r1);
+                const double r2 = r1 - from_bf16(mid);
+                const uint16_t lo = to_bf16(r2);
+                term[0][p] = from_bf16(lo); term[1][p] = from_bf16(mid); term[2][p] = from_bf16(hi);
+                split_res += std::fabs(kmat[p] - (term[0][p] + term[1][p] + term[2][p]));
+                // scatter into the A-operand order: chain H, matrix row R, k-step s, lane (hk, R), element j
+                const int h = z >> 5, H = (z >> 4) & 1, r = z & 15;
+                const int R = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int s = p >> 4, hk = (p >> 3) & 1, j = p & 7;
+                const int lane = 32 * hk + R;
+                const uint16_t t3[3] = {lo, mid, hi};
+                for (int t = 0; t < 3; ++t) af[((((size_t)t * 2 + H) * 4 + s) * 64 + lane) * 8 + j] = t3[t];
+            }
+        // reference evaluation error (same expression as derive_quant_consts)
+        double wsum = 0, run = 0, adds = 0;
+        for (int j = 0; j < 64; ++j) { const double w = std::fabs(kmat[j]); wsum += w; run += w; if (j >= 1) adds += run; }
+        const double e_ref = (2.0 * kU * kPmax * wsum + kU * kPmax * adds) * 1.001;
+        // accumulation bound, MFMA order: terms lo, mid, hi; k-steps 0..3 inside each
+        double acc = 0, e_mfma = 0;
+        for (int t = 0; t < 3; ++t)
+            for (int s = 0; s < 4; ++s) {
+                double sm = 0;
+                for (int j = 0; j < 16; ++j) sm += std::fabs(term[t][16 * s + j]) * kPmax;
+                e_mfma += 2.0 * 16.0 * kU * (acc + sm) * 1.0001;
+                acc += sm;
+            }
+        const float cu = u == 0 ? 0.707107f : 1.0f, cv = v == 0 ? 0.707107f : 1.0f;
+        const double K = (double)((0.25f * cu) * cv);
+        const double q = (double)table[k];
+        const double zmax = K * kPmax * wsum / q;
+        const double delta = (K / q) * (e_ref + e_mfma + kPmax * split_res) + 4.0 * kU * (zmax + 1.0);
+        delta_z[z] = delta;
+        if (z > 0 && delta > dmax) dmax = delta;
+        mt->qmul[z] = (float)(K / q);
+        mt->qstep[z] = (float)table[k];
+        if (delta_out) delta_out[k] = delta;
+    }
+    mt->bias = (float)(0.5 + dmax * 1.001 + 1.0e-7);
+    const double db = (double)mt->bias - 0.5;
+    for (int z = 0; z < 64; ++z) mt->qthr[z] = (float)(db + delta_z[z] * 1.001 + 1.0e-7);
+}
+
 #include "std_table_consts.inc"
 
 bool std_consts_match_baked(const uint8_t table[64]) {
