@@ -45,6 +45,11 @@ struct JpegAmdEncoder {
     bool use_mfma = true;        // matrix-pipe transform kernel (JPEGAMD_KERNEL=aan|generic selects the register AAN kernel)
     bool force_generic = false;  // JPEGAMD_KERNEL=generic: AAN kernel with run-time constants even for the reference table
     MfmaTables *tables_dev = nullptr;
+    uint8_t *seg_tail = nullptr;                // last 7 bits of every segment (matrix-pipe kernel)
+    uint32_t *chunk_ff = nullptr;               // finalize kernels: per-chunk 0xFF totals and bit offsets
+    unsigned long long *chunk_b0 = nullptr;
+    bool use_finalize = true;                   // JPEGAMD_POST=split selects the 4-kernel post-processing
+    int last_segs = 0;
     unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-segment phase cycle sums
     uint8_t qtable[64];
     QuantConsts qc;
@@ -135,6 +140,10 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY(hipMalloc((void **)&e->prefix, 512));
     HIP_TRY(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
     HIP_TRY(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
+    HIP_TRY(hipMalloc((void **)&e->seg_tail, (size_t)e->max_segs + 16));
+    HIP_TRY(hipMalloc((void **)&e->chunk_ff, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->chunk_b0, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(unsigned long long)));
+    if (const char *post = std::getenv("JPEGAMD_POST")) e->use_finalize = std::strcmp(post, "split") != 0;
     if (std::getenv("JPEGAMD_STAMPS")) {
         HIP_TRY(hipMalloc((void **)&e->stamps_dev, (size_t)e->max_segs * 16 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(e->stamps_dev, 0, (size_t)e->max_segs * 16 * sizeof(unsigned long long)));
@@ -157,7 +166,7 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (!e) return JPEGAMD_OK;
     if (e->pending) hipStreamSynchronize(e->last_stream);
     free_scratch(e);
-    hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev);
+    hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev); hipFree(e->chunk_ff); hipFree(e->chunk_b0); hipFree(e->seg_tail);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e;
     return JPEGAMD_OK;
@@ -245,18 +254,27 @@ static TransformOut transform_out(const JpegAmdEncoder *e) {
     return t;
 }
 
+static FinReset fin_reset(const JpegAmdEncoder *e, int num_segs) {
+    FinReset r;
+    (void)num_segs;
+    r.stats = e->stats_dev;
+    return r;
+}
+
 static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
                                 void *stream) {
     if (e->use_mfma) {
         TransformOutM to;
         std::memset(&to, 0, sizeof(to));
         to.seg_words = e->seg_words; to.seg_bits = e->seg_bits; to.seg_syms = e->seg_syms; to.seg_exact = e->seg_exact;
-        to.huff = e->huff; to.tables = e->tables_dev; to.stamps = e->stamps_dev;
+        to.huff = e->huff; to.tables = e->tables_dev; to.stamps = e->stamps_dev; to.seg_tail = e->seg_tail;
         to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
+        to.reset = fin_reset(e, im.num_segs);
         return launch_transform_mfma(im, to, taps, stream);
     }
     TransformOut to = transform_out(e);
     to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
+    to.reset = fin_reset(e, im.num_segs);
     return launch_transform(im, e->qc, to, taps, e->std_kernel, e->entropy_backend, stream);
 }
 
@@ -281,22 +299,37 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
     }
     if (launch_any_transform(e, im, false, nullptr, nullptr, nullptr, stream)) return JPEGAMD_ERR_HIP;
     if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
-    if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
-        return JPEGAMD_ERR_HIP;
-
-    PackArgs pa;
-    std::memset(&pa, 0, sizeof(pa));
-    pa.seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
-    pa.seg_words = e->seg_words; pa.seg_bits = e->seg_bits; pa.seg_bitstart = e->seg_bitstart;
-    pa.seg_ff = e->seg_ff; pa.seg_ffstart = e->seg_ffstart; pa.num_segs = im.num_segs;
-    pa.out = (uint8_t *)out_dev; pa.out_capacity = out_capacity; pa.out_size = out_size_dev; pa.stats = e->stats_dev;
-    pa.prefix = e->prefix; pa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
-    pa.write_eoi = with_container ? 1 : 0;
-    if (launch_count_ff(pa, stream)) return JPEGAMD_ERR_HIP;
-    if (launch_scan_ff(e->seg_ff, e->seg_ffstart, im.num_segs, e->stats_dev, stream)) return JPEGAMD_ERR_HIP;
-    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
-    if (launch_pack(pa, stream)) return JPEGAMD_ERR_HIP;
+    const uint32_t seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
+    if (e->use_finalize) {
+        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+        FinalizeArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.seg_words = e->seg_words; fa.seg_stride = seg_stride; fa.seg_bits = e->seg_bits;
+        fa.seg_tail = e->use_mfma ? e->seg_tail : nullptr;
+        fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
+        fa.out = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size = out_size_dev; fa.stats = e->stats_dev;
+        fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
+        fa.write_eoi = with_container ? 1 : 0;
+        fa.seg_ff = e->seg_ff; fa.chunk_ff = e->chunk_ff; fa.chunk_b0 = e->chunk_b0;
+        if (launch_finalize(fa, stream)) return JPEGAMD_ERR_HIP;
+    } else {
+        if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
+            return JPEGAMD_ERR_HIP;
+        PackArgs pa;
+        std::memset(&pa, 0, sizeof(pa));
+        pa.seg_stride = seg_stride;
+        pa.seg_words = e->seg_words; pa.seg_bits = e->seg_bits; pa.seg_bitstart = e->seg_bitstart;
+        pa.seg_ff = e->seg_ff; pa.seg_ffstart = e->seg_ffstart; pa.num_segs = im.num_segs;
+        pa.out = (uint8_t *)out_dev; pa.out_capacity = out_capacity; pa.out_size = out_size_dev; pa.stats = e->stats_dev;
+        pa.prefix = e->prefix; pa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
+        pa.write_eoi = with_container ? 1 : 0;
+        if (launch_count_ff(pa, stream)) return JPEGAMD_ERR_HIP;
+        if (launch_scan_ff(e->seg_ff, e->seg_ffstart, im.num_segs, e->stats_dev, stream)) return JPEGAMD_ERR_HIP;
+        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+        if (launch_pack(pa, stream)) return JPEGAMD_ERR_HIP;
+    }
     if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
+    e->last_segs = im.num_segs;
 
     e->last_stream = stream;
     e->pending = true;
@@ -307,6 +340,8 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
 extern "C" int32_t jpegamd_encoder_finish(JpegAmdEncoder *e, JpegAmdStats *stats) {
     if (!e) return JPEGAMD_ERR_ARG;
     if (!e->pending) return JPEGAMD_ERR_ARG;
+    if (stats && e->use_finalize)       // symbol / exact-path totals are only summed when somebody asks
+        if (launch_sum_stats(e->seg_syms, e->seg_exact, e->last_segs, e->stats_dev, e->last_stream)) return JPEGAMD_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(e->last_stream));
     e->pending = false;
     HIP_TRY(hipMemcpy(&e->mirror, e->stats_dev, sizeof(ScanStats), hipMemcpyDeviceToHost));

@@ -1,0 +1,274 @@
+// jpegamd_finalize.hip -- everything after the transform: bit offsets of the segments, 0xFF counting,
+// stuffing offsets, byte stitching / stuffing, container.  Two launches, no inter-workgroup waits:
+//
+//   k_fin_count  workgroup = 16 consecutive segments (one per wave).  All bit counts are final when the
+//                kernel starts, so the chunk's bit offset is simply the sum of every earlier segment's
+//                count (a few tens of KB from L2, no scan chain).  With the offset -- hence the byte
+//                phase -- known, each wave counts the 0xFF bytes it OWNS (a byte belongs to the segment
+//                holding its last bit) and the workgroup records its bit offset and 0xFF total.
+//   k_fin_write  sums the earlier chunks' 0xFF totals, then every wave writes its owned bytes at
+//                prefix + byte index + stuffing offset, 0x00 after each 0xFF (huffman.c:26-32); the wave
+//                owning the last segment adds the zero-padded final byte (huffman.c:65-81), EOI
+//                (jpeg_handler.c:113-117) and the size.  Every output byte is written by exactly one
+//                lane with a plain store: no atomics, no pre-zeroing.
+//
+// Both kernels are latency-bound (3 MB of payload), so they front-load every global read whose address
+// does not depend on data (own / previous segment's bit count, the segment's words into LDS, the
+// predecessor sums) and keep dependent round trips to two.
+#include "jpegamd_device.h"
+
+namespace jpegamd {
+
+constexpr int kFinWaves = 16;                                  // segments per workgroup
+constexpr int kFinCache = 256;                                 // segment words kept in LDS per wave (typical segment: ~90)
+
+__device__ __forceinline__ uint32_t fin_bits_at(const uint32_t *__restrict__ w, uint32_t pos, int nbits /*1..8*/) {
+    const uint32_t i = pos >> 5, sh = pos & 31u;
+    const uint64_t win = ((uint64_t)w[i] << 32) | w[i + 1];
+    return (uint32_t)((win << sh) >> (64 - nbits));
+}
+
+// The `need` (1..7) bits that precede segment `s` in the stream (s may equal num_segs).
+__device__ __forceinline__ uint32_t fin_tail_bits(const FinalizeArgs &a, int s, int need) {
+    uint32_t val = 0;
+    int got = 0;
+    for (int sp = s - 1; got < need && sp >= 0; --sp) {
+        const uint32_t tp = a.seg_bits[sp];
+        const int take = min(need - got, (int)tp);
+        if (take > 0) {
+            val |= fin_bits_at(a.seg_words + (size_t)sp * a.seg_stride, tp - (uint32_t)take, take) << got;
+            got += take;
+        }
+    }
+    return val;
+}
+
+// 64-bit block sum of one value per thread (values < 2^40), result to every thread.
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long part, unsigned long long *s_part /*[kFinWaves]*/) {
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t plo = (uint32_t)wave_sum_i32((int)(uint32_t)(part & 0xFFFFFFu));
+    const uint32_t phi = (uint32_t)wave_sum_i32((int)(uint32_t)(part >> 24));
+    if (lane == 0) s_part[wave] = (unsigned long long)plo + ((unsigned long long)phi << 24);
+    __syncthreads();
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < kFinWaves; ++w) t += s_part[w];
+    __syncthreads();
+    return t;
+}
+
+// Per-wave view of one segment: its place in the stream and byte access through the LDS copy.
+struct FinSeg {
+    const uint32_t *words;      // global
+    const uint32_t *cache;      // LDS copy of the first kFinCache words
+    unsigned long long b0, b1;
+    uint32_t nown, leadbits;
+    int lead;
+    __device__ __forceinline__ uint32_t bits_at(uint32_t pos, int nbits) const {
+        const uint32_t i = pos >> 5, sh = pos & 31u;
+        uint32_t w0, w1;
+        if (i + 1 < (uint32_t)kFinCache) { w0 = cache[i]; w1 = cache[i + 1]; } else { w0 = words[i]; w1 = words[i + 1]; }
+        return (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> (64 - nbits));
+    }
+    __device__ __forceinline__ uint32_t owned_byte(uint32_t r) const {
+        if (r == 0 && lead) return (leadbits << (8 - lead)) | bits_at(0, 8 - lead);
+        return bits_at(8u * r - (uint32_t)lead, 8);
+    }
+};
+
+// Stage the wave's segment into LDS and fetch what the leading partial byte needs from the previous segment.
+// Nothing here waits for a loaded value before issuing the next load: the first 128 words are requested
+// unconditionally (the per-segment reservation is far larger), the rest only for unusually long segments.
+__device__ __forceinline__ void fin_stage(const FinalizeArgs &a, int s, bool have, uint32_t my_bits, uint32_t *cache, int lane,
+                                          uint32_t *prev_bits, uint32_t *prev_tail7) {
+    const uint32_t *words = a.seg_words + (size_t)(have ? s : 0) * a.seg_stride;
+    const uint32_t w0 = words[lane], w1 = words[64 + lane];
+    uint32_t pb = 0, pt = 0;
+    if (have && s > 0) {
+        pb = a.seg_bits[s - 1];
+        if (a.seg_tail) pt = a.seg_tail[s - 1];                    // written by the transform kernel
+        else if (pb >= 7) pt = fin_bits_at(a.seg_words + (size_t)(s - 1) * a.seg_stride, pb - 7u, 7);
+    }
+    cache[lane] = w0;
+    cache[64 + lane] = w1;
+    const uint32_t nw = have ? min((my_bits + 31u) / 32u + 1u, (uint32_t)kFinCache) : 0u;
+    for (uint32_t j = 128u + (uint32_t)lane; j < nw; j += 64) cache[j] = words[j];
+    *prev_bits = pb;
+    *prev_tail7 = pt;
+}
+
+__device__ __forceinline__ FinSeg fin_view(const FinalizeArgs &a, int s, bool have, unsigned long long b0, uint32_t my_bits,
+                                           const uint32_t *cache, uint32_t prev_bits, uint32_t prev_tail7) {
+    FinSeg v;
+    v.words = a.seg_words + (size_t)(have ? s : 0) * a.seg_stride;
+    v.cache = cache;
+    v.b0 = b0;
+    v.b1 = b0 + my_bits;
+    v.nown = have ? (uint32_t)((v.b1 >> 3) - (b0 >> 3)) : 0u;
+    v.lead = (int)(b0 & 7u);
+    v.leadbits = 0;
+    if (have && v.lead) v.leadbits = prev_bits >= 7 ? (prev_tail7 & ((1u << v.lead) - 1u)) : fin_tail_bits(a, s, v.lead);
+    return v;
+}
+
+__global__ __launch_bounds__(64 * kFinWaves) void k_fin_count(const FinalizeArgs a) {
+    __shared__ uint32_t s_seg[kFinWaves][kFinCache];
+    __shared__ uint32_t s_cnt[kFinWaves];
+    __shared__ unsigned long long s_part[kFinWaves];
+
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int g = (int)blockIdx.x;
+    const int s = g * kFinWaves + wave;
+    const bool have = s < a.num_segs;
+
+    const uint32_t my_bits = have ? a.seg_bits[s] : 0u;
+    uint32_t prev_bits, prev_tail7;
+    fin_stage(a, s, have, my_bits, s_seg[wave], lane, &prev_bits, &prev_tail7);
+
+    // bit offset of the chunk: sum of all earlier segments (16 g values, g*16 % 4 == 0)
+    unsigned long long part = 0;
+    {
+        const int n_before = g * kFinWaves, step = 64 * kFinWaves * 4;
+        for (int i = (int)threadIdx.x * 4; i < n_before; i += 4 * step) {          // up to 4 loads in flight per trip
+            uint4 q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                q[k] = (i + k * step < n_before) ? *reinterpret_cast<const uint4 *>(a.seg_bits + i + k * step) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part += (unsigned long long)q[k].x + q[k].y + q[k].z + q[k].w;
+        }
+    }
+    if (lane == 0) s_cnt[wave] = my_bits;
+    const unsigned long long chunk_b0 = block_sum_u64(part, s_part);     // (syncs: s_cnt is visible afterwards)
+    uint32_t before = 0;
+    for (int w = 0; w < wave; ++w) before += s_cnt[w];
+    const FinSeg v = fin_view(a, s, have, chunk_b0 + before, my_bits, s_seg[wave], prev_bits, prev_tail7);
+
+    int ffc = 0;
+    for (uint32_t r = (uint32_t)lane; r < v.nown; r += 64) ffc += (v.owned_byte(r) == 0xFFu) ? 1 : 0;
+    ffc = wave_sum_i32(ffc);
+    __syncthreads();
+    if (lane == 0) { s_cnt[wave] = (uint32_t)ffc; if (have) a.seg_ff[s] = (uint32_t)ffc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < kFinWaves; ++w) t += s_cnt[w];
+        a.chunk_ff[g] = t;
+        a.chunk_b0[g] = chunk_b0;
+    }
+}
+
+__global__ __launch_bounds__(64 * kFinWaves) void k_fin_write(const FinalizeArgs a) {
+    __shared__ uint32_t s_seg[kFinWaves][kFinCache];
+    __shared__ unsigned long long s_part[kFinWaves];
+
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int g = (int)blockIdx.x;
+    const int s = g * kFinWaves + wave;
+    const bool have = s < a.num_segs;
+
+    if (g == 0 && a.prefix_len > 0)                             // JFIF prefix (jpeg_handler.c:220-233)
+        for (int i = (int)threadIdx.x; i < a.prefix_len; i += 64 * kFinWaves)
+            if ((uint64_t)i < a.out_capacity) a.out[i] = a.prefix[i];
+
+    const uint32_t my_bits = have ? a.seg_bits[s] : 0u;
+    uint32_t prev_bits, prev_tail7;
+    fin_stage(a, s, have, my_bits, s_seg[wave], lane, &prev_bits, &prev_tail7);
+    // offsets inside the chunk: bits and 0xFF counts of the chunk's earlier segments
+    uint32_t b_in, ff_in;                                       // every wave: lane w loads segment w of the chunk, DPP scan
+    {
+        const int sp = g * kFinWaves + lane;
+        const bool in = lane < kFinWaves && sp < a.num_segs;
+        const uint32_t vb = in ? a.seg_bits[sp] : 0u, vf = in ? a.seg_ff[sp] : 0u;
+        const uint32_t ib = wave_incl_scan_u32(vb), iff = wave_incl_scan_u32(vf);
+        b_in = (uint32_t)__builtin_amdgcn_readlane((int)(ib - vb), wave);
+        ff_in = (uint32_t)__builtin_amdgcn_readlane((int)(iff - vf), wave);
+    }
+    // stuffed bytes in front of the chunk
+    unsigned long long part = 0;
+    for (int i = (int)threadIdx.x; i < g; i += 4 * 64 * kFinWaves) {
+        uint32_t q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = (i + k * 64 * kFinWaves < g) ? a.chunk_ff[i + k * 64 * kFinWaves] : 0u;
+        part += (unsigned long long)q[0] + q[1] + q[2] + q[3];
+    }
+    const unsigned long long chunk_ff0 = block_sum_u64(part, s_part);
+    if (!have) return;
+    const FinSeg v = fin_view(a, s, have, a.chunk_b0[g] + b_in, my_bits, s_seg[wave], prev_bits, prev_tail7);
+
+    const uint64_t base = (uint64_t)a.prefix_len + (v.b0 >> 3) + chunk_ff0 + ff_in;
+    uint32_t running = 0;
+    bool overflow = false;
+    for (uint32_t r0 = 0; r0 < v.nown; r0 += 64) {
+        const uint32_t r = r0 + (uint32_t)lane;
+        const bool valid = r < v.nown;
+        const uint32_t byte = valid ? v.owned_byte(r) : 0u;
+        const bool isff = valid && byte == 0xFFu;
+        const unsigned long long m = __ballot(isff);
+        const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint64_t pos = base + r + running + before;
+        if (valid) {
+            if (pos + (isff ? 2u : 1u) <= a.out_capacity) {
+                a.out[pos] = (uint8_t)byte;
+                if (isff) a.out[pos + 1] = 0x00;               // huffman.c:29-31
+            } else {
+                overflow = true;
+            }
+        }
+        running += (uint32_t)__popcll(m);
+    }
+    if (__any(overflow) && lane == 0) atomicOr(&a.stats->status, 1u);
+
+    if (s == a.num_segs - 1 && lane == 0) {
+        uint64_t end = base + v.nown + running;
+        const int rem = (int)(v.b1 & 7u);
+        bool ok = true;
+        if (rem) {                                              // zero-padded flush (huffman.c:65-81)
+            const uint32_t bits = fin_tail_bits(a, a.num_segs, rem);
+            if (end < a.out_capacity) a.out[end] = (uint8_t)(bits << (8 - rem)); else ok = false;
+            ++end;
+        }
+        if (a.write_eoi) {                                      // jpeg_handler.c:113-117
+            if (end + 2 <= a.out_capacity) { a.out[end] = 0xFF; a.out[end + 1] = 0xD9; } else ok = false;
+            end += 2;
+        }
+        if (!ok) atomicOr(&a.stats->status, 1u);
+        *a.out_size = end;
+        a.stats->out_size = end;
+        a.stats->total_bits = v.b1;
+        a.stats->total_ff = chunk_ff0 + ff_in + running;
+    }
+}
+
+int launch_finalize(const FinalizeArgs &a, void *stream) {
+    hipLaunchKernelGGL(k_fin_count, dim3(a.num_chunks), dim3(64 * kFinWaves), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_fin_write, dim3(a.num_chunks), dim3(64 * kFinWaves), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}
+
+// Sums of the per-segment symbol / exact-path counters, on request (jpegamd_encoder_finish with stats).
+__global__ __launch_bounds__(1024) void k_sum_stats(const uint32_t *__restrict__ seg_syms, const uint32_t *__restrict__ seg_exact,
+                                                     int n, ScanStats *stats) {
+    __shared__ unsigned long long s_part[2][16];
+    unsigned long long a = 0, b = 0;
+    for (int i = (int)threadIdx.x; i < n; i += 1024) { a += seg_syms[i]; b += seg_exact[i]; }
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+    if (lane == 0) { s_part[0][wave] = a; s_part[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long ta = 0, tb = 0;
+        for (int w = 0; w < 16; ++w) { ta += s_part[0][w]; tb += s_part[1][w]; }
+        stats->total_syms = ta;
+        stats->total_exact = tb;
+    }
+}
+
+int launch_sum_stats(const uint32_t *seg_syms, const uint32_t *seg_exact, int n, ScanStats *stats, void *stream) {
+    hipLaunchKernelGGL(k_sum_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, seg_syms, seg_exact, n, stats);
+    return (int)hipGetLastError();
+}
+
+int finalize_chunks(int num_segs) { return (num_segs + kFinWaves - 1) / kFinWaves; }
+
+}  // namespace jpegamd

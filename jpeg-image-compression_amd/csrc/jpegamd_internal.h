@@ -57,6 +57,44 @@ struct MfmaTables {
     float pad[3];
 };
 
+struct ScanStats {                   // device-side per-call record (scan kernels + k_pack)
+    uint64_t total_bits;
+    uint64_t total_syms;
+    uint64_t total_exact;
+    uint64_t total_ff;
+    uint64_t out_size;               // copy of *out_size (k_pack)
+    uint32_t status;                 // bit0 = output capacity overflow; zeroed by the bit scan
+    uint32_t pad;
+};
+
+// What a transform kernel clears for the finalize kernels that follow it on the stream.
+struct FinReset {
+    ScanStats *stats;           // status word
+};
+
+// Post-processing (jpegamd_finalize.hip): bit / stuffing offsets + stitch + stuffing + container, 2 launches.
+struct FinalizeArgs {
+    const uint32_t *seg_words;
+    uint32_t seg_stride;
+    const uint32_t *seg_bits;
+    const uint8_t *seg_tail;        // [num_segs] last 7 bits of each segment (null: read them from seg_words)
+    int32_t num_segs;
+    int32_t num_chunks;             // workgroups = ceil(num_segs / 16)
+    uint8_t *out;
+    uint64_t out_capacity;
+    uint64_t *out_size;             // device
+    ScanStats *stats;               // device
+    const uint8_t *prefix;
+    int32_t prefix_len;
+    int32_t write_eoi;
+    uint32_t *seg_ff;               // [num_segs]  owned 0xFF bytes per segment   (k_fin_count -> k_fin_write)
+    uint32_t *chunk_ff;             // [num_chunks] 0xFF bytes per chunk
+    unsigned long long *chunk_b0;   // [num_chunks] bit offset of the chunk
+};
+int launch_finalize(const FinalizeArgs &a, void *stream);
+int launch_sum_stats(const uint32_t *seg_syms, const uint32_t *seg_exact, int n, ScanStats *stats, void *stream);
+int finalize_chunks(int num_segs);
+
 struct ImageDesc {
     const uint8_t *pixels;
     int32_t width, height, row_stride, bottom_up;
@@ -76,16 +114,7 @@ struct TransformOut {
     int8_t *tap_y;
     int16_t *tap_zz;
     uint64_t *tap_mask;
-};
-
-struct ScanStats {                   // device-side per-call record (scan kernels + k_pack)
-    uint64_t total_bits;
-    uint64_t total_syms;
-    uint64_t total_exact;
-    uint64_t total_ff;
-    uint64_t out_size;               // copy of *out_size (k_pack)
-    uint32_t status;                 // bit0 = output capacity overflow; zeroed by the bit scan
-    uint32_t pad;
+    FinReset reset;            // cleared by workgroup 0
 };
 
 struct PackArgs {
@@ -119,9 +148,11 @@ int launch_pack(const PackArgs &a, void *stream);
 struct TransformOutM {          // like TransformOut, for the matrix-pipe kernel (segments of 128 blocks)
     uint32_t *seg_words;        // [num_segs][kSegCapWordsM]
     uint32_t *seg_bits, *seg_syms, *seg_exact;
+    uint8_t *seg_tail;          // [num_segs] last 7 bits of the segment's bit string (for the next segment's first byte)
     const uint32_t *huff;       // [272]
     const MfmaTables *tables;   // device copy
     unsigned long long *stamps; // [num_segs][16] per-phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
+    FinReset reset;             // cleared by workgroup 0
     int8_t *tap_y;
     int16_t *tap_zz;
     uint64_t *tap_mask;

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64 * kWavesPerGroup) JPEGAMD_OCCUPANCY void k_trans
     {
         const int t = (int)threadIdx.x;
         s_huff[t] = out.huff[t];
+        if (blockIdx.x == 0 && t == 0 && out.reset.stats) out.reset.stats->status = 0u;   // cleared for this call's finalize kernels
         if (t < 16) s_huff[256 + t] = out.huff[256 + t];
         if (t < 64) s_cos[t] = kCosFM[t];
     }

@@ -34,14 +34,23 @@ constexpr int kItemCapM = 512;
 constexpr uint32_t kItemDcM = 0x80000000u;
 
 struct WaveLdsM {
-    uint32_t items[kItemCapM];        // (DC flag | zigzag position << 16 | value16)
+    uint32_t items[kItemCapM + 64 + 2];   // [0] = 0 sentinel, then (DC flag | zigzag position << 16 | value16); +64 read slack
     uint32_t win[128];                // bit window being assembled
 };
 
 // 8 pixels (24 bytes, 4-byte aligned) -> 8 centred luma values as bf16.  The -128 rides in the dot
 // product's accumulator (C = -32768 = -128 * 256), so (int)dot >> 8 is Y - 128 (converter.c:51,84-86).
-__device__ __forceinline__ bf16x8 luma_row8_bf16(const uint32_t *__restrict__ src, uint32_t w) {
-    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4], d5 = src[5];
+struct RawRow { uint32_t d[6]; };      // one block row: 8 pixels x 3 bytes
+
+__device__ __forceinline__ RawRow load_raw_row(const uint32_t *__restrict__ src) {
+    RawRow r;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.d[i] = src[i];
+    return r;
+}
+
+__device__ __forceinline__ bf16x8 luma_row8_bf16(const RawRow &raw, uint32_t w) {
+    const uint32_t d0 = raw.d[0], d1 = raw.d[1], d2 = raw.d[2], d3 = raw.d[3], d4 = raw.d[4], d5 = raw.d[5];
     const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu;
     const uint32_t wA = w, wB0 = c0 << 24, wB1 = c1 | (c2 << 8), wC0 = (c0 << 16) | (c1 << 24), wC1 = c2, wD = w << 8;
     const uint32_t kC = 0xFFFF8000u;
@@ -95,6 +104,7 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
             s_cos[t] = kCosFM[t];
         }
         if (t < 272) s_huff[t] = out.huff[t];
+        if (blockIdx.x == 0 && t == 0 && out.reset.stats) out.reset.stats->status = 0u;   // cleared for this call's finalize kernels
     }
     __syncthreads();
 
@@ -128,9 +138,25 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
     uint32_t *segw = out.seg_words + (size_t)seg * kSegCapWordsM;
-    uint32_t carry_bits = 0, wbase = 0;
+    uint32_t carry_bits = 0, wbase = 0, last_word = 0;          // last_word: the most recent COMPLETE word of the bit string
     int nsym = 0, nexact = 0;
-    if (lane == 0) wl.win[0] = 0u;
+    if (lane == 0) { wl.win[0] = 0u; wl.items[0] = 0u; }
+
+    // Pixel rows of the NEXT tile are requested while the current tile is being coded (the raw registers
+    // are free once the luma conversion is done), so HBM latency hides behind the entropy phases.
+    const auto tile_interior = [&](int tb0) {
+        const int nb = min(kTileBlocks, seg_nblk - tb0);
+        return im.fast_ok && ((sbx0 + tb0 + nb) * 8 <= im.width) && (py0 + 8 <= im.height);
+    };
+    const auto request_rows = [&](int tb0, RawRow (&raw)[4]) {
+        const int nb = min(kTileBlocks, seg_nblk - tb0);
+        const int pbx = sbx0 + tb0 + min(b, nb - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            raw[s] = load_raw_row(reinterpret_cast<const uint32_t *>(row_ptr(im, py0 + 2 * s + h) + 24 * (size_t)pbx));
+    };
+    RawRow raw[4];
+    if (tile_interior(0)) request_rows(0, raw);
 
 #pragma unroll 1
     for (int tb0 = 0; tb0 < seg_nblk; tb0 += kTileBlocks) {
@@ -142,11 +168,10 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
         STAMP(0);   // tile prologue / previous tile's tail
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         bf16x8 bfrag[4];
-        const bool interior = im.fast_ok && ((sbx0 + tb0 + nblk) * 8 <= im.width) && (py0 + 8 <= im.height);
+        const bool interior = tile_interior(tb0);
         if (interior) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                bfrag[s] = luma_row8_bf16(reinterpret_cast<const uint32_t *>(row_ptr(im, py0 + 2 * s + h) + 3 * (size_t)px0), im.weights);
+            for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_bf16(raw[s], im.weights);
         } else {
             // edge tile (right/bottom replication, converter.c:31,36) or unaligned source: clamped byte gather
 #pragma unroll
@@ -155,6 +180,7 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
                 for (int j = 0; j < 8; ++j)
                     bfrag[s][j] = (__bf16)(float)(luma_clamped(im, px0 + j, py0 + 2 * s + h) - 128);
         }
+        if (tb0 + kTileBlocks < seg_nblk && tile_interior(tb0 + kTileBlocks)) request_rows(tb0 + kTileBlocks, raw);
         if (kTaps && active && out.tap_y) {
             int8_t *ty = out.tap_y + ((size_t)by * im.blocks_w + bx) * 64;
 #pragma unroll
@@ -275,7 +301,7 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
             const uint32_t gt = gend - gbase;
 
             if (mine) {
-                uint32_t ptr = my_base - gbase;
+                uint32_t ptr = my_base - gbase + 1u;           // items[0] is the "previous item" of the first one
                 const uint32_t zhi = (uint32_t)(32 * h) << 16;
                 if (h == 0) wl.items[ptr++] = kItemDcM | (uint32_t)(dc_diff & 0xFFFF);      // rle.c:68-76
 #pragma unroll
@@ -292,8 +318,8 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
             for (uint32_t b0 = 0; b0 < gt; b0 += 64) {
                 const uint32_t idx = b0 + (uint32_t)lane;
                 const bool valid = idx < gt;
-                const uint32_t it = valid ? wl.items[idx] : 0u;
-                const uint32_t itp = (valid && idx > 0) ? wl.items[idx - 1] : 0u;
+                const uint32_t itp = wl.items[idx];              // previous item (sentinel 0 in front of the first)
+                const uint32_t it = wl.items[idx + 1];           // reads past the list are masked by `valid`
                 const int v = (int)(short)(it & 0xFFFFu);
                 const bool isdc = (it & kItemDcM) != 0u;
                 const int run = v ? (int)((it >> 16) & 0x7Fu) - (int)((itp >> 16) & 0x7Fu) - 1 : 0;   // EOB: symbol 0x00
@@ -306,7 +332,8 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
                 const int zrl = (valid && !isdc) ? (run >> 4) : 0;                                    // rle.c:99-103
                 hi <<= (32 - len) & 31;
                 if (len == 0) hi = 0;
-                if (__builtin_expect(__any(zrl != 0), 0)) {
+                const bool any_zrl = __any(zrl != 0);
+                if (__builtin_expect(any_zrl, 0)) {
                     const uint32_t zw = s_huff[0xF0];
                     const uint32_t zc = zw & 0xFFFFu;
                     const int zl = (int)(zw >> 16);
@@ -319,24 +346,24 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
                     len = tot;
                     nsym += zrl;
                 }
-                const uint32_t incl_b = wave_incl_scan_u32((uint32_t)len, lane);
+                const uint32_t incl_b = wave_incl_scan_u32((uint32_t)len);
                 const uint32_t batch_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl_b, 63);
                 const uint32_t rel = carry_bits + incl_b - (uint32_t)len - wbase * 32u;
                 wl.win[1 + lane] = 0u;
-                if (lane < 63) wl.win[65 + lane] = 0u;
-                if (len) {
+                wl.win[65 + (lane < 63 ? lane : 62)] = 0u;
+                {   // empty symbols OR zeros into an in-range word: no divergence
                     const uint32_t w = rel >> 5, sh = rel & 31u;
                     atomicOr(&wl.win[w], __builtin_amdgcn_alignbit(0u, hi, sh));
-                    const uint32_t w1 = __builtin_amdgcn_alignbit(hi, lo, sh);
-                    if (w1) atomicOr(&wl.win[w + 1], w1);
-                    const uint32_t w2 = __builtin_amdgcn_alignbit(lo, 0u, sh);
-                    if (w2) atomicOr(&wl.win[w + 2], w2);
+                    atomicOr(&wl.win[w + 1], __builtin_amdgcn_alignbit(hi, lo, sh));
+                    if (__builtin_expect(any_zrl, 0)) atomicOr(&wl.win[w + 2], __builtin_amdgcn_alignbit(lo, 0u, sh));
                 }
                 carry_bits += batch_bits;
                 const uint32_t done = (carry_bits >> 5) - wbase;
-                if ((uint32_t)lane < done) segw[wbase + lane] = wl.win[lane];
-                if ((uint32_t)lane + 64u < done) segw[wbase + 64u + lane] = wl.win[64 + lane];
-                const uint32_t part = wl.win[done];
+                const uint32_t out0 = wl.win[lane], out1 = wl.win[64 + lane], part = wl.win[done];   // one LDS round trip
+                if ((uint32_t)lane < done) segw[wbase + lane] = out0;
+                if ((uint32_t)lane + 64u < done) segw[wbase + 64u + lane] = out1;
+                if (done) last_word = done > 64u ? (uint32_t)__builtin_amdgcn_readlane((int)out1, (int)done - 65)
+                                                 : (uint32_t)__builtin_amdgcn_readlane((int)out0, (int)done - 1);
                 if (lane == 0) wl.win[0] = part;
                 wbase += done;
             }
@@ -352,6 +379,10 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
 #endif
     const int seg_syms = wave_sum_i32(nsym);
     if (lane == 0) {
+        // last 7 bits of the string = what the next segment's first output byte may start with
+        const uint32_t p = carry_bits & 31u, w0 = wl.win[0];
+        const uint32_t tail = p ? ((last_word << p) | (w0 >> (32u - p))) : last_word;
+        if (out.seg_tail) out.seg_tail[seg] = (uint8_t)(tail & 0x7Fu);
         out.seg_bits[seg] = carry_bits;
         out.seg_syms[seg] = (uint32_t)seg_syms;
         out.seg_exact[seg] = (uint32_t)nexact;
