@@ -46,6 +46,10 @@ struct JpegAmdEncoder {
     bool force_generic = false;  // JPEGAMD_KERNEL=generic: AAN kernel with run-time constants even for the reference table
     MfmaTables *tables_dev = nullptr;
     uint8_t *seg_tail = nullptr;                // last 7 bits of every segment (matrix-pipe kernel)
+    bool split_pipeline = true;                 // tile transform + entropy kernels (JPEGAMD_KERNEL=mfma-fused: one kernel)
+    uint32_t *tile_items = nullptr, *tile_count = nullptr, *tile_exact = nullptr;
+    int32_t *tile_lastdc = nullptr;
+    int max_tiles = 0;
     uint32_t *chunk_ff = nullptr;               // finalize kernels: per-chunk 0xFF totals and bit offsets
     unsigned long long *chunk_b0 = nullptr;
     bool use_finalize = true;                   // JPEGAMD_POST=split selects the 4-kernel post-processing
@@ -141,6 +145,11 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
     HIP_TRY(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
     HIP_TRY(hipMalloc((void **)&e->seg_tail, (size_t)e->max_segs + 16));
+    e->max_tiles = ((max_height + 7) / 8) * (((max_width + 7) / 8 + kTileBlocks - 1) / kTileBlocks);
+    HIP_TRY(hipMalloc((void **)&e->tile_items, (size_t)e->max_tiles * kTileItemCap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->tile_count, (size_t)e->max_tiles * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->tile_exact, (size_t)e->max_tiles * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void **)&e->tile_lastdc, (size_t)e->max_tiles * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&e->chunk_ff, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->chunk_b0, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(unsigned long long)));
     if (const char *post = std::getenv("JPEGAMD_POST")) e->use_finalize = std::strcmp(post, "split") != 0;
@@ -153,6 +162,7 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     if (const char *force = std::getenv("JPEGAMD_KERNEL")) {
         e->force_generic = std::strcmp(force, "generic") == 0;
         e->use_mfma = !(e->force_generic || std::strcmp(force, "aan") == 0);
+        e->split_pipeline = std::strcmp(force, "mfma-fused") != 0;
     }
     if (const char *ent = std::getenv("JPEGAMD_ENTROPY")) e->entropy_backend = std::strcmp(ent, "lane") == 0 ? 0 : 1;
     uint32_t words[272];
@@ -167,6 +177,7 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (e->pending) hipStreamSynchronize(e->last_stream);
     free_scratch(e);
     hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev); hipFree(e->chunk_ff); hipFree(e->chunk_b0); hipFree(e->seg_tail);
+    hipFree(e->tile_items); hipFree(e->tile_count); hipFree(e->tile_exact); hipFree(e->tile_lastdc);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e;
     return JPEGAMD_OK;
@@ -238,6 +249,8 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
                                                          : (77u | (150u << 8) | (29u << 16));
     d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row,
                            (e && e->use_mfma) ? kSegBlocksM : kSegBlocks);
+    d->tiles_per_row = (d->blocks_w + kTileBlocks - 1) / kTileBlocks;
+    d->num_tiles = d->tiles_per_row * d->blocks_h;
     d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0) ? 1 : 0;
     if (e && d->num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
     return JPEGAMD_OK;
@@ -270,7 +283,16 @@ static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool tap
         to.huff = e->huff; to.tables = e->tables_dev; to.stamps = e->stamps_dev; to.seg_tail = e->seg_tail;
         to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
         to.reset = fin_reset(e, im.num_segs);
-        return launch_transform_mfma(im, to, taps, stream);
+        if (!e->split_pipeline) return launch_transform_mfma(im, to, taps, stream);
+        to.tile_items = e->tile_items; to.tile_count = e->tile_count; to.tile_lastdc = e->tile_lastdc; to.tile_exact = e->tile_exact;
+        if (int err = launch_tile_transform(im, to, taps, stream)) return err;
+        EntropyArgs ea;
+        std::memset(&ea, 0, sizeof(ea));
+        ea.tile_items = e->tile_items; ea.tile_count = e->tile_count; ea.tile_exact = e->tile_exact; ea.tile_lastdc = e->tile_lastdc;
+        ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
+        ea.seg_words = e->seg_words; ea.seg_bits = e->seg_bits; ea.seg_syms = e->seg_syms; ea.seg_exact = e->seg_exact;
+        ea.seg_tail = e->seg_tail;
+        return launch_entropy(ea, stream);
     }
     TransformOut to = transform_out(e);
     to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;

@@ -47,6 +47,8 @@ constexpr int kSegTiles = 4;                         // tiles per segment (= per
 constexpr int kSegBlocksM = kTileBlocks * kSegTiles; // 128
 constexpr int kSegCapWordsM = ((kSegBlocksM * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64;
 constexpr int kAFragWords = 3 * 2 * 4 * 64 * 4;      // [term][chain][kstep][lane] x 8 bf16 = 24 KiB
+// split pipeline (jpegamd_tile_pipeline.hip): per-tile symbol lists in HBM; slot 0 is a sentinel, 64 words of read slack
+constexpr int kTileItemCap = (1 + kTileBlocks * 65 + 64 + 63) / 64 * 64;   // 2176
 
 struct MfmaTables {
     uint32_t afrag[kAFragWords];   // LUT-product matrix, 3-way bf16 split (lo, mid, hi), MFMA A-operand order
@@ -100,6 +102,7 @@ struct ImageDesc {
     int32_t width, height, row_stride, bottom_up;
     uint32_t weights;          // luma weights for stored bytes 0,1,2 (byte 3 = 0)
     int32_t blocks_w, blocks_h, segs_per_row, num_segs;
+    int32_t tiles_per_row, num_tiles;   // 32-block tiles (matrix-pipe kernels)
     int32_t fast_ok;           // pixels % 4 == 0 && row_stride % 4 == 0
 };
 
@@ -152,12 +155,27 @@ struct TransformOutM {          // like TransformOut, for the matrix-pipe kernel
     const uint32_t *huff;       // [272]
     const MfmaTables *tables;   // device copy
     unsigned long long *stamps; // [num_segs][16] per-phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
+    // split pipeline only: per-tile outputs of k_tile_transform
+    uint32_t *tile_items;       // [num_tiles][kTileItemCap]
+    uint32_t *tile_count;       // [num_tiles] items in the list
+    int32_t *tile_lastdc;       // [num_tiles] quantised DC of the tile's last block
+    uint32_t *tile_exact;       // [num_tiles] coefficients recomputed in exact order
     FinReset reset;             // cleared by workgroup 0
     int8_t *tap_y;
     int16_t *tap_zz;
     uint64_t *tap_mask;
 };
 int launch_transform_mfma(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream);
+int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream);
+struct EntropyArgs {            // k_entropy: per-tile symbol lists -> per-segment bit strings
+    const uint32_t *tile_items, *tile_count, *tile_exact;
+    const int32_t *tile_lastdc;
+    const uint32_t *huff;
+    int32_t num_segs, segs_per_row, tiles_per_row;
+    uint32_t *seg_words, *seg_bits, *seg_syms, *seg_exact;
+    uint8_t *seg_tail;
+};
+int launch_entropy(const EntropyArgs &a, void *stream);
 int launch_dct_exact(const int8_t *blocks, float *coeffs, int64_t nblocks, void *stream);
 
 // ---- host-side constant derivation (quant_consts.cpp) ----------------------------------

@@ -195,15 +195,15 @@ __global__ __launch_bounds__(64 * kWavesM) __attribute__((amdgpu_waves_per_eu(JP
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll 1
-        for (int t = 0; t < 3; ++t) {          // rolled: keeps at most 8 A fragments (32 VGPRs) in flight
-            const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];
+        for (int t = 0; t < 3; ++t) {          // rolled: one term's 8 A fragments (32 VGPRs) are fetched together,
+            const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];     // so the 8 MFMAs issue back to back
+            bf16x8 afr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) afr[i] = *reinterpret_cast<const bf16x8 *>(&at[(i * 64) * 4]);   // i = H * 4 + s
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int H = 0; H < 2; ++H) {
-                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(&at[((H * 4 + s) * 64) * 4]);
-                    acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[s], acc[H], 0, 0, 0);
-                }
+                for (int H = 0; H < 2; ++H) acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[H * 4 + s], bfrag[s], acc[H], 0, 0, 0);
         }
 
         { float ck_ = acc[0][0] + acc[1][15]; asm volatile("" ::"v"(ck_)); }
