@@ -156,6 +156,9 @@ uint64_t jpegamd_synth_bmp(int32_t width, int32_t height, uint32_t seed, int32_t
 int32_t jpegamd_debug_quant_consts(int32_t quality, float *mult, float *bias, float *thr, double *delta,
                                    uint8_t *table);
 
+/* Same for the matrix-pipe kernel (constants indexed by ZIGZAG position; one bias for all; delta by raster k). */
+int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, float *bias, double *delta);
+
 const char *jpegamd_version(void);
 
 /* ------------------------------------------------------------------------------------

@@ -96,6 +96,19 @@ extern "C" int32_t jpegamd_debug_quant_consts(int32_t quality, float *mult, floa
     return JPEGAMD_OK;
 }
 
+extern "C" int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, float *bias, double *delta) {
+    uint8_t t[64];
+    static MfmaTables mt;
+    double d[64];
+    quant_table_for_quality(quality, t);
+    derive_mfma_tables(t, &mt, d);
+    if (qmul) std::memcpy(qmul, mt.qmul, sizeof(mt.qmul));
+    if (qthr) std::memcpy(qthr, mt.qthr, sizeof(mt.qthr));
+    if (bias) *bias = mt.bias;
+    if (delta) std::memcpy(delta, d, sizeof(d));
+    return JPEGAMD_OK;
+}
+
 extern "C" uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return 0;
     const uint64_t nb = (uint64_t)((width + 7) / 8) * (uint64_t)((height + 7) / 8);
@@ -477,6 +490,7 @@ int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64
     rc = describe(e, img, &im);
     if (rc) return rc;
     im.blocks_w = 1; im.blocks_h = 1; im.segs_per_row = 1; im.num_segs = 1;   // block (0,0) only
+    im.tiles_per_row = 1; im.num_tiles = 1;
     int8_t *y_dev = nullptr; int16_t *zz_dev = nullptr; float *dct_dev = nullptr;
     HIP_TRY(hipMalloc((void **)&y_dev, 64));
     HIP_TRY(hipMalloc((void **)&zz_dev, 128));

@@ -74,6 +74,7 @@ def _load() -> C.CDLL:
         "jpegamd_synth_bmp": (u64, [i32, i32, C.c_uint32, i32, C.c_uint32, vp, u64]),
         "jpegamd_version": (C.c_char_p, []),
         "jpegamd_debug_quant_consts": (i32, [i32, vp, vp, vp, vp, vp]),
+        "jpegamd_debug_mfma_consts": (i32, [i32, vp, vp, vp, vp]),
         "JpegCompression_Init": (i32, []),
         "JpegCompression_DeInit": (i32, []),
         "JpegCompression_Reserve": (i32, [i32, i32]),
@@ -94,7 +95,7 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async "
             "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
-            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
+            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts jpegamd_debug_mfma_consts JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
             "jpegamd_encode_bmp_memory jpegamd_parse_bmp").split()
 
@@ -107,6 +108,15 @@ def quant_consts(quality: int = 50):
     lib.jpegamd_debug_quant_consts(quality, mult.ctypes.data, bias.ctypes.data, thr.ctypes.data, delta.ctypes.data,
                                    table.ctypes.data)
     return dict(mult=mult, bias=bias, thr=thr, delta=delta, table=table)
+
+
+def mfma_consts(quality: int = 50):
+    """Constants of the matrix-pipe kernel: qmul/qthr float32[64] by zigzag position, bias, delta float64[64] by raster k."""
+    import numpy as np
+    qmul, qthr = np.zeros(64, np.float32), np.zeros(64, np.float32)
+    bias, delta = np.zeros(1, np.float32), np.zeros(64, np.float64)
+    lib.jpegamd_debug_mfma_consts(quality, qmul.ctypes.data, qthr.ctypes.data, bias.ctypes.data, delta.ctypes.data)
+    return dict(qmul=qmul, qthr=qthr, bias=float(bias[0]), delta=delta)
 
 
 def version() -> str:

@@ -80,6 +80,26 @@ def test_quant_constants_match_python_derivation(jpegamd):
     assert list(t50[:8]) == [16, 11, 10, 16, 24, 40, 51, 61] and list(jpegamd.quant_consts(0)["table"]) == list(t50)
 
 
+def test_mfma_constants_are_on_the_safe_side(jpegamd, oracle):
+    """Matrix-pipe kernel: threshold >= (bias - 0.5) + delta for every coefficient, bias - 0.5 >= every delta, the
+    multiplier is K/q (the MFMA output is the plain LUT sum), and delta is never below the reference-evaluation
+    part of the AAN kernel's bound minus its LUT term (the MFMA path evaluates the LUT products themselves)."""
+    zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    for q in (50, 10, 90):
+        c = jpegamd.mfma_consts(q)
+        table = oracle.quant_table(q)
+        db = np.float64(np.float32(c["bias"])) - 0.5
+        for z in range(64):
+            k = zz[z]
+            assert db >= c["delta"][k] or z == 0
+            assert np.float64(c["qthr"][z]) >= db + c["delta"][k]
+            u, v = divmod(k, 8)
+            kk = np.float32(np.float32(np.float32(0.25) * (np.float32(0.707107) if u == 0 else np.float32(1))) * (np.float32(0.707107) if v == 0 else np.float32(1)))
+            assert abs(float(c["qmul"][z]) - float(kk) / float(table[k])) <= 1e-7 * float(kk)
+        assert 1e-5 < c["delta"][1:].max() < 5e-3
+
+
 def test_guard_band_holds_on_float32_emulation(jpegamd, oracle):
     """Emulate the kernel's fast path in numpy float32 (every op rounded separately: the worst case for
     the bound) and check against the oracle: a coefficient the guard does NOT flag must already equal the
