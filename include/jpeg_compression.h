@@ -84,9 +84,9 @@ typedef struct JpegAmdStats {
     uint64_t entropy_bits;      /* unstuffed entropy-coded bits */
     uint64_t stuffed_bytes;     /* number of 0x00 bytes inserted after 0xFF */
     uint64_t exact_fallbacks;   /* coefficients recomputed in the reference's float order */
-    uint64_t ns_transform;      /* fused luma+DCT+quant+zigzag+RLE/Huffman-symbol kernel */
-    uint64_t ns_scan;           /* bit-offset / stuffing prefix sums */
-    uint64_t ns_pack;           /* bitstream stitch + 0xFF stuffing + container */
+    uint64_t ns_transform;      /* luma + DCT + quantisation + zigzag + symbol lists (k_tile_transform, or the fused kernel) */
+    uint64_t ns_entropy;        /* run/size symbols -> Huffman bit strings per segment (k_entropy; 0 when fused) */
+    uint64_t ns_pack;           /* bit / stuffing offsets, stitch, 0xFF stuffing, container (k_fin_count + k_fin_write) */
     uint64_t ns_total;
 } JpegAmdStats;
 
@@ -190,12 +190,12 @@ typedef struct JPEG_COMPRESSION_DTO {
     uint64_t huff_phy_ptr;    /* DEVICE address receiving the entropy-coded segment */
     uint32_t huff_size;       /* IN: capacity in bytes; OUT: bytes written */
 
-    uint64_t cycles_color_conversion; /* OUT, ns: the five per-block stages run fused, so */
-    uint64_t cycles_dct;              /*   cycles_dct carries the fused kernel's time and  */
-    uint64_t cycles_quantization;     /*   the other four fused-stage fields are 0         */
+    uint64_t cycles_color_conversion; /* OUT, ns: colour, DCT, quantisation and zigzag run fused in one  */
+    uint64_t cycles_dct;              /*   kernel: cycles_dct carries its time, the other three are 0    */
+    uint64_t cycles_quantization;
     uint64_t cycles_zigzag;
-    uint64_t cycles_rle;
-    uint64_t cycles_huffman;          /* OUT, ns: scan + pack kernels */
+    uint64_t cycles_rle;              /* OUT, ns: symbol kernel (run/size + Huffman codes per segment)   */
+    uint64_t cycles_huffman;          /* OUT, ns: offsets + stitch + stuffing kernels */
     uint64_t cycles_total;            /* OUT, ns */
 
     /* MI355X additions */

@@ -213,7 +213,7 @@ static int32_t read_slot(JpegAmdEncoder *e, int slot, JpegAmdStats *stats) {
     hipEvent_t *ev = e->ring[(size_t)slot].ev;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); stats->ns_transform = (uint64_t)((double)ms * 1e6);
-    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->ns_scan = (uint64_t)((double)ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->ns_entropy = (uint64_t)((double)ms * 1e6);
     HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ns_pack = (uint64_t)((double)ms * 1e6);
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3])); stats->ns_total = (uint64_t)((double)ms * 1e6);
     return JPEGAMD_OK;
@@ -270,7 +270,7 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
 }
 
 static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
-                                void *stream);
+                                void *stream, hipEvent_t mid = nullptr);
 
 static TransformOut transform_out(const JpegAmdEncoder *e) {
     TransformOut t;
@@ -288,7 +288,8 @@ static FinReset fin_reset(const JpegAmdEncoder *e, int num_segs) {
 }
 
 static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
-                                void *stream) {
+                                void *stream, hipEvent_t mid) {
+    // `mid` (optional) is recorded after the transform proper, before the symbol kernel of the split pipeline
     if (e->use_mfma) {
         TransformOutM to;
         std::memset(&to, 0, sizeof(to));
@@ -296,9 +297,14 @@ static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool tap
         to.huff = e->huff; to.tables = e->tables_dev; to.stamps = e->stamps_dev; to.seg_tail = e->seg_tail;
         to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
         to.reset = fin_reset(e, im.num_segs);
-        if (!e->split_pipeline) return launch_transform_mfma(im, to, taps, stream);
+        if (!e->split_pipeline) {
+            const int err = launch_transform_mfma(im, to, taps, stream);
+            if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
+            return err;
+        }
         to.tile_items = e->tile_items; to.tile_count = e->tile_count; to.tile_lastdc = e->tile_lastdc; to.tile_exact = e->tile_exact;
         if (int err = launch_tile_transform(im, to, taps, stream)) return err;
+        if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
         EntropyArgs ea;
         std::memset(&ea, 0, sizeof(ea));
         ea.tile_items = e->tile_items; ea.tile_count = e->tile_count; ea.tile_exact = e->tile_exact; ea.tile_lastdc = e->tile_lastdc;
@@ -310,7 +316,9 @@ static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool tap
     TransformOut to = transform_out(e);
     to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
     to.reset = fin_reset(e, im.num_segs);
-    return launch_transform(im, e->qc, to, taps, e->std_kernel, e->entropy_backend, stream);
+    const int aan_err = launch_transform(im, e->qc, to, taps, e->std_kernel, e->entropy_backend, stream);
+    if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
+    return aan_err;
 }
 
 extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *img, void *out_dev,
@@ -332,8 +340,7 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         ++e->calls;
         HIP_TRY(hipEventRecord(ev[0], stream));
     }
-    if (launch_any_transform(e, im, false, nullptr, nullptr, nullptr, stream)) return JPEGAMD_ERR_HIP;
-    if (timed) HIP_TRY(hipEventRecord(ev[1], stream));
+    if (launch_any_transform(e, im, false, nullptr, nullptr, nullptr, stream, timed ? ev[1] : nullptr)) return JPEGAMD_ERR_HIP;
     const uint32_t seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
     if (e->use_finalize) {
         if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
@@ -348,6 +355,7 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         fa.seg_ff = e->seg_ff; fa.chunk_ff = e->chunk_ff; fa.chunk_b0 = e->chunk_b0;
         if (launch_finalize(fa, stream)) return JPEGAMD_ERR_HIP;
     } else {
+        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
         if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
             return JPEGAMD_ERR_HIP;
         PackArgs pa;
@@ -360,7 +368,6 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         pa.write_eoi = with_container ? 1 : 0;
         if (launch_count_ff(pa, stream)) return JPEGAMD_ERR_HIP;
         if (launch_scan_ff(e->seg_ff, e->seg_ffstart, im.num_segs, e->stats_dev, stream)) return JPEGAMD_ERR_HIP;
-        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
         if (launch_pack(pa, stream)) return JPEGAMD_ERR_HIP;
     }
     if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
@@ -533,8 +540,8 @@ extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
     dto->cycles_dct = st.ns_transform;
     dto->cycles_quantization = 0;
     dto->cycles_zigzag = 0;
-    dto->cycles_rle = 0;
-    dto->cycles_huffman = st.ns_scan + st.ns_pack;
+    dto->cycles_rle = st.ns_entropy;
+    dto->cycles_huffman = st.ns_pack;
     dto->cycles_total = st.ns_total;
 
     // First-block debug taps (jpeg_compression.c:150-169), host pointers.

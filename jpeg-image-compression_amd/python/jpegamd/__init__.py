@@ -34,7 +34,7 @@ class Image(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("jfif_bytes", "entropy_bits", "stuffed_bytes", "exact_fallbacks",
-                                          "ns_transform", "ns_scan", "ns_pack", "ns_total")]
+                                          "ns_transform", "ns_entropy", "ns_pack", "ns_total")]
 
 
 class DTO(C.Structure):
