@@ -142,6 +142,13 @@ __device__ __forceinline__ float exact_term_sum(float t) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc), 63));
 }
 
+// floor(x) as int32 in one instruction (v_cvt_flr_i32_f32); x comes from an ordinary VALU op (no software hazard)
+__device__ __forceinline__ int floor_to_int(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ float exact_coef_float(float pixel /*lane j: p[x=j>>3][y=j&7]*/, int u, int v,
                                                   const float *s_cos, int lane) {
     const float cx = s_cos[u * 8 + (lane >> 3)];     // COS_LUT[x][u]

@@ -57,6 +57,7 @@ struct MfmaTables {
     float qstep[64];               // (float) q, by zigzag position
     float bias;                    // 0.5 + max_z delta_z
     float pad[3];
+    float grp_thr[8];              // grouped layout: [group G][lane half h], |LUT sum| below it => zigzag 16G+8h .. +7 all quantise to an unflagged 0
 };
 
 struct ScanStats {                   // device-side per-call record (scan kernels + k_pack)
@@ -157,6 +158,7 @@ struct TransformOutM {          // like TransformOut, for the matrix-pipe kernel
     unsigned long long *stamps; // [num_segs][16] per-phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
     // split pipeline only: per-tile outputs of k_tile_transform
     uint32_t *tile_items;       // [num_tiles][kTileItemCap]
+    uint32_t *tile_ctr;         // [64 groups][32 words]: word 0 ticket counter of the dynamic tile hand-out, word 1 waves finished; zero between launches
     uint32_t *tile_count;       // [num_tiles] items in the list
     int32_t *tile_lastdc;       // [num_tiles] quantised DC of the tile's last block
     uint32_t *tile_exact;       // [num_tiles] coefficients recomputed in exact order
@@ -182,7 +184,8 @@ int launch_dct_exact(const int8_t *blocks, float *coeffs, int64_t nblocks, void 
 void quant_table_for_quality(int quality, uint8_t table[64]);
 void derive_quant_consts(const uint8_t table[64], QuantConsts *qc, double delta_out[64]);
 void derive_std_consts(const uint8_t table[64], StdConsts *sc);
-void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64] /*by raster k, may be null*/);
+void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64] /*by raster k, may be null*/,
+                        bool grouped = false /*A-row order of the split pipeline: lane (h), site s <-> zigzag 16(s>>3)+8h+(s&7)*/);
 bool std_consts_match_baked(const uint8_t table[64]);   // table is the reference's AND baked == derived
 void build_huffman_words(uint32_t words[272]);
 size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]);

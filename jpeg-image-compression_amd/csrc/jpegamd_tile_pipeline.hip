@@ -24,6 +24,10 @@ namespace jpegamd {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
+#ifndef JPEGAMD_AFR_BATCH
+#define JPEGAMD_AFR_BATCH 2
+#endif
+constexpr int kAfrBatch = JPEGAMD_AFR_BATCH;   // k-steps whose A fragments (2 x 4 VGPRs each) are in registers at once
 constexpr int kWavesT = 8;                      // 512-thread workgroups share the 24 KiB matrix image in LDS
 constexpr uint32_t kItDc = 0x80000000u;         // item is a DC difference
 constexpr uint32_t kItFirst = 0x40000000u;      // ... of the first block of its tile: value is the absolute DC
@@ -58,17 +62,55 @@ __device__ __forceinline__ bf16x8 luma_row8_bf16(const RawRow &raw, uint32_t w) 
 }
 
 
+// In-kernel phase stamps (diagnostic builds only: -DJPEGAMD_STAMPS; the shipped kernel executes none).
+// Unlike the fused kernel's stamps these do NOT drain vmcnt, so the prefetch / store overlap stays as shipped;
+// a phase is charged with whatever its own s_waitcnt instructions wait for.
+#ifdef JPEGAMD_STAMPS
+#define TSTAMP(i)                                                                             \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t_;                                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+        st_sum[i] += t_ - st_last;                                                            \
+        st_last = t_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#elif defined(JPEGAMD_MARKS)      // static instruction census: markers in the .s file (tools/isa_census.py)
+#define TSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " #i ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
+constexpr int kTileGroups = 64;                 // ticket counters (one cache line each) of the dynamic tile hand-out
+// 0: rows are requested at the top of their own tile and the other waves of the SIMD cover the latency;
+// 1: the next tile's pixel rows are requested right after the luma step (24 live VGPRs across the whole body: spills);
+// 2: ... requested after the exact-order step, in flight during the counts and appends.
+#ifndef JPEGAMD_TILE_PREFETCH
+#define JPEGAMD_TILE_PREFETCH 0
+#endif
 #ifndef JPEGAMD_TILE_WAVES
 #define JPEGAMD_TILE_WAVES 4
 #endif
 
+struct TileSched {            // division-free launch geometry, filled by launch_tile_transform
+    int32_t grp_shift;        // workgroups form 1 << grp_shift ticket groups (blockIdx & mask)
+    int32_t tiles_per_group;  // contiguous tiles owned by a group
+    uint32_t tpr_magic;       // floor(2^32 / tiles_per_row) + 1: tile / tiles_per_row by multiply-high (+ one correction)
+};
+
 template <bool kTaps>
 __global__ __launch_bounds__(64 * kWavesT) __attribute__((amdgpu_waves_per_eu(JPEGAMD_TILE_WAVES, JPEGAMD_TILE_WAVES)))
-void k_tile_transform(const ImageDesc im, const TransformOutM out) {
+void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSched sch) {
     __shared__ __attribute__((aligned(16))) uint32_t s_afrag[kAFragWords];
     __shared__ float2 s_q[64];                 // (multiplier, threshold) by zigzag position
     __shared__ float s_qstep[64];
     __shared__ float s_cos[64];
+    __shared__ float s_grp[8];                 // [group][h]: |acc| below this => every site of the group quantises to an unflagged 0
+    // The tile's centred luma (bf16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
+    // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
+    // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
+    // prefetched rows of the NEXT tile as well: ~40 % of a tile's time per event (tools/stamp_profile_tile.py).
+    __shared__ __attribute__((aligned(16))) uint32_t s_pix[kWavesT][8 * 132];
 
     {
         const int t = (int)threadIdx.x;
@@ -79,27 +121,43 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out) {
             s_q[t] = make_float2(out.tables->qmul[t], out.tables->qthr[t]);
             s_qstep[t] = out.tables->qstep[t];
             s_cos[t] = kCosFM[t];
+            if (t < 8) s_grp[t] = out.tables->grp_thr[t];
         }
         if (blockIdx.x == 0 && t == 0 && out.reset.stats) out.reset.stats->status = 0u;   // cleared for this call's finalize kernels
     }
     __syncthreads();
 
     const int lane = lane_id();
-    const int wave = (int)(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
     const int h = lane >> 5, b = lane & 31;
     const float bias = out.tables->bias;
-    const float2 *sq_lane = &s_q[32 * h];
+    const float2 *sq_lane = &s_q[8 * h];
 
     // Persistent waves: tile = first, first + stride, ...  The matrix image is loaded once per workgroup and the
     // NEXT tile's pixel rows are requested as soon as the current ones are converted, so their HBM latency
     // hides behind the MFMA / quantise / append phases of the current tile.
-    const int stride = (int)gridDim.x * kWavesT;
-    const int first = (int)blockIdx.x * kWavesT + wave;
+    // Tile hand-out.  Per-tile time varies a lot with content (symbols per tile: mean 127, std 91 on the bench
+    // image; exact-order events), so a static split of 8 tiles per wave leaves SIMDs idle behind the slowest wave
+    // (per-wave totals: max/mean 1.5, tools/stamp_profile_tile.py).  One global ticket per tile is no answer
+    // either: same-address device atomics retire at ~12 ns each (measured: 6x slower).  So the workgroups form
+    // kTileGroups groups (blockIdx % groups: the members of a group sit on one XCD), each group owns a contiguous
+    // range of tiles and hands them to its waves through its OWN ticket counter (own cache line).  The ticket for
+    // the tile after next is requested one iteration ahead, so its latency is hidden like the pixel rows'.
+    const int groups = 1 << sch.grp_shift;
+    const int grp = (int)blockIdx.x & (groups - 1);
+    const int grp_waves = ((((int)gridDim.x - 1 - grp) >> sch.grp_shift) + 1) * kWavesT;   // waves of this group
+    const int grp_lo = min(grp * sch.tiles_per_group, im.num_tiles);
+    const int grp_hi = min(grp_lo + sch.tiles_per_group, im.num_tiles);
+    uint32_t *ctr = out.tile_ctr + grp * 32;                                                // [0] tickets, [1] waves done
+    const int first = grp_lo + ((int)blockIdx.x >> sch.grp_shift) * kWavesT + wave;
+    const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
     struct TileGeo { int by, tbx0, nblk, bx; bool interior; };
     const auto geo = [&](int tile) {
         TileGeo g;
-        g.by = tile / im.tiles_per_row;
-        g.tbx0 = (tile - g.by * im.tiles_per_row) * kTileBlocks;
+        int q = (int)__umulhi((uint32_t)tile, sch.tpr_magic), r = tile - q * im.tiles_per_row;   // tile / tiles_per_row
+        if (r >= im.tiles_per_row) { ++q; r -= im.tiles_per_row; }
+        g.by = q;
+        g.tbx0 = r * kTileBlocks;
         g.nblk = min(kTileBlocks, im.blocks_w - g.tbx0);
         g.bx = g.tbx0 + min(b, g.nblk - 1);                     // idle columns shadow the last block
         g.interior = im.fast_ok && ((g.tbx0 + g.nblk) * 8 <= im.width) && (g.by * 8 + 8 <= im.height);
@@ -111,18 +169,30 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out) {
             raw[s] = load_raw_row(reinterpret_cast<const uint32_t *>(row_ptr(im, g.by * 8 + 2 * s + h) + 24 * (size_t)g.bx));
     };
     RawRow raw[4];
-    if (first < im.num_tiles) { const TileGeo g0 = geo(first); if (g0.interior) request_rows(g0, raw); }
+    TileGeo tg = geo(first < grp_hi ? first : 0);
+#if JPEGAMD_TILE_PREFETCH
+    if (first < grp_hi && tg.interior) request_rows(tg, raw);
+#endif
+    int nxt = first < grp_hi ? grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket()) : grp_hi;
+#ifdef JPEGAMD_STAMPS
+    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
 
 #pragma unroll 1
-    for (int tile = first; tile < im.num_tiles; tile += stride) {
-        const TileGeo tg = geo(tile);
-        const int by = tg.by, tbx0 = tg.tbx0, nblk = tg.nblk, bx = tg.bx;
+    for (int tile = first; tile < grp_hi;) {
+        const uint32_t ticket_v = ticket();                   // consumed at the bottom of the iteration
+        const int by = tg.by, nblk = tg.nblk, bx = tg.bx;
         const int py0 = by * 8, px0 = bx * 8;
         const bool active = b < nblk, interior = tg.interior;
         int nexact = 0;
+        TSTAMP(0);   // loop overhead / geometry
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         bf16x8 bfrag[4];
         if (interior) {
+#if !JPEGAMD_TILE_PREFETCH
+            request_rows(tg, raw);
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_bf16(raw[s], im.weights);
         } else {
@@ -133,7 +203,16 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out) {
                 for (int j = 0; j < 8; ++j)
                     bfrag[s][j] = (__bf16)(float)(luma_clamped(im, px0 + j, py0 + 2 * s + h) - 128);
         }
-        if (tile + stride < im.num_tiles) { const TileGeo gn = geo(tile + stride); if (gn.interior) request_rows(gn, raw); }
+        TSTAMP(1);   // wait for the prefetched rows + luma
+        TileGeo tg_next = tg;                                 // one division per tile: the geometry is carried over
+#if JPEGAMD_TILE_PREFETCH == 1
+        if (nxt < grp_hi) { tg_next = geo(nxt); if (tg_next.interior) request_rows(tg_next, raw); }
+#else
+        if (nxt < grp_hi) tg_next = geo(nxt);
+#endif
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x8 *>(&s_pix[wave][(2 * s + h) * 132 + b * 4]) = bfrag[s];
+        TSTAMP(2);   // issue of the next tile's loads
         if (kTaps && active && out.tap_y) {
             int8_t *ty = out.tap_y + ((size_t)by * im.blocks_w + bx) * 64;
 #pragma unroll
@@ -144,41 +223,82 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out) {
 
         // ---- 2. the 64x64 transform on the matrix pipe: small terms first ----------------------
         f32x16 acc[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll 1
-        for (int t = 0; t < 3; ++t) {          // rolled: one term's 8 A fragments (32 VGPRs) are fetched together,
-            const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];     // so the 8 MFMAs issue back to back
-            bf16x8 afr[8];
+        for (int t = 0; t < 3; ++t) {          // rolled; the A fragments of one term are fetched kAfrBatch at a time so that
+            const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];     // the MFMAs issue back to back behind ONE wait
 #pragma unroll
-            for (int i = 0; i < 8; ++i) afr[i] = *reinterpret_cast<const bf16x8 *>(&at[(i * 64) * 4]);   // i = H * 4 + s
-            __builtin_amdgcn_sched_barrier(0);     // keep the 8 LDS reads ahead of the MFMAs (hipcc otherwise sinks each read next to its use)
+            for (int s0 = 0; s0 < 4; s0 += kAfrBatch) {
+                bf16x8 afr[2][kAfrBatch];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int H = 0; H < 2; ++H)
 #pragma unroll
-                for (int H = 0; H < 2; ++H) acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[H * 4 + s], bfrag[s], acc[H], 0, 0, 0);
+                    for (int i = 0; i < kAfrBatch; ++i) afr[H][i] = *reinterpret_cast<const bf16x8 *>(&at[((H * 4 + s0 + i) * 64) * 4]);
+                __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMAs (hipcc otherwise sinks each read next to its use)
+#pragma unroll
+                for (int i = 0; i < kAfrBatch; ++i)
+#pragma unroll
+                    for (int H = 0; H < 2; ++H) {
+                        if (t == 0 && s0 + i == 0) {       // C = 0 as an inline constant: no accumulator clearing
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[H][i], bfrag[0], zero, 0, 0, 0);
+                        } else {
+                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[H][i], bfrag[s0 + i], acc[H], 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
-        // ---- 3. quantise with the guard band ---------------------------------------------------
-        // Branch-free: a lane's flagged sites are collected in a 32-bit mask (bit 16H + r) so the 32 LDS
-        // constant reads can be batched by the compiler; the rare exact-order path runs once afterwards.
-        int n[2][16];
-        // DC (zigzag 0, lanes h == 0): the sum is an exact integer, so the reference's value is reproducible directly
-        const int dc_exact = ref_quantise(__fmul_rn(ref_scale(0, 0), acc[0][0]), s_qstep[0]);
-        uint32_t flagbits = 0;
+        TSTAMP(3);   // MFMA
+        // ---- 3. quantise with the guard band, one GROUP of 8 sites at a time -----------------------
+        // Site s = 16H + r of lane (h, b) holds zigzag position 16 * (s >> 3) + 8 * h + (s & 7): group G = s >> 3
+        // covers zigzag 16G .. 16G + 15 across the two lanes of a block.  Every instruction of any wave costs one
+        // 4-cycle issue slot of its SIMD (measured: +256 scalar or vector instructions per tile both cost +16 us),
+        // so the kernel is bound by its instruction count, and in photo-like content most tiles have NO non-zero
+        // coefficient in the higher groups: one max|acc| test (5 instructions) skips the quantiser, the counts
+        // and the appends of such a group (11+ instructions per site).
+#define JPEGAMD_ACC(site) acc[(site) >> 4][(site) & 15]
+        int n[32];
+        uint32_t flagbits = 0;                                      // bit s: site s of this lane is within delta of a rounding tie
+        bool gact[4];
 #pragma unroll
-        for (int H = 1; H >= 0; --H)
+        for (int G = 0; G < 4; ++G) {
+            gact[G] = true;
+            if (G > 0) {                                            // |acc| below the group's zero threshold in every lane?
+                float m = fmaxf(fabsf(JPEGAMD_ACC(8 * G)), fabsf(JPEGAMD_ACC(8 * G + 1)));
 #pragma unroll
-            for (int r = 15; r >= 0; --r) {                       // descending: the shift-in below leaves site s at bit s
-                const float2 q = sq_lane[16 * H + r];
-                const float zc = fmaf(acc[H][r], q.x, bias);      // z + 0.5 + delta
-                const float g = __builtin_amdgcn_fractf(zc);
-                n[H][r] = (int)floorf(zc);
-                flagbits = (flagbits << 1) | ((g <= q.y) ? 1u : 0u);   // within delta of a rounding tie
-                if ((r & 7) == 0) __builtin_amdgcn_sched_barrier(0);   // at most 8 constant pairs in flight
+                for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(JPEGAMD_ACC(8 * G + j)));
+                gact[G] = __ballot(m >= s_grp[2 * G + h]) != 0ull;
             }
-        if (h == 0) { n[0][0] = dc_exact; flagbits &= ~1u; }     // DC lanes never need the fallback
-        if (!active) flagbits = 0;
+            if (gact[G]) {
+                uint32_t gb = 0;
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {                      // descending: the carry shift-in leaves site j at bit j
+                    const int st = 8 * G + j;
+                    const float2 q = sq_lane[16 * G + j];
+                    const float zc = fmaf(JPEGAMD_ACC(st), q.x, bias);      // z + 0.5 + delta
+                    n[st] = floor_to_int(zc);
+                    gb = gb + gb + ((__builtin_amdgcn_fractf(zc) <= q.y) ? 1u : 0u);   // one v_addc: within delta of a tie
+                }
+                flagbits |= gb << (8 * G);
+            } else if (kTaps) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) n[8 * G + j] = 0;
+            }
+        }
+        // DC (zigzag 0, lanes h == 0): its LUT sum is an exact integer, so the reference's value follows from two
+        // float operations in the lane itself -- done only when some DC sits within delta of a tie (ties are
+        // frequent here: sum * (K/q) is a multiple of ~1/128 at Q=50), never through the cooperative path.
+        {
+            const bool dcflag = (h == 0) && (flagbits & 1u);
+            if (__ballot(dcflag) != 0ull) {
+                const int dc_exact = ref_quantise(__fmul_rn(ref_scale(0, 0), acc[0][0]), s_qstep[0]);
+                if (dcflag) n[0] = dc_exact;
+            }
+            if (h == 0) flagbits &= ~1u;
+        }
+        if (!active) flagbits = 0u;
+        TSTAMP(4);   // quantise
 
         // ---- 4. exact-order recomputation of flagged coefficients ------------------------------
         uint64_t exact_mask = 0;
@@ -189,20 +309,25 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out) {
                 fm &= fm - 1;
                 uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)flagbits, fl);
                 while (bits) {
-                    const int site = __ffs((int)bits) - 1;
+                    const int st = __ffs((int)bits) - 1;
                     bits &= bits - 1;
-                    const int z = 32 * (fl >> 5) + site;
+                    const int z = 16 * (st >> 3) + 8 * (fl >> 5) + (st & 7);
                     const int k = kZZ[z], u = k >> 3, v = k & 7;
-                    const int ebx = tbx0 + (fl & 31);
-                    const float pix = (float)(luma_clamped(im, ebx * 8 + (lane & 7), py0 + (lane >> 3)) - 128);
+                    const uint32_t pw = s_pix[wave][(lane >> 3) * 132 + (fl & 31) * 4 + ((lane & 7) >> 1)];
+                    const float pix = __builtin_bit_cast(float, (lane & 1) ? (pw & 0xFFFF0000u) : (pw << 16));   // bf16 -> f32
                     const float coef = exact_coef_float(pix, u, v, s_cos, lane);
                     const int val = ref_quantise(coef, s_qstep[z]);
                     ++nexact;
                     if (kTaps && lane == fl) exact_mask |= 1ull << k;
-#pragma unroll
-                    for (int H = 0; H < 2; ++H)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) n[H][r] = (site == 16 * H + r && lane == fl) ? val : n[H][r];
+                    const int jj = st & 7;
+                    switch (st >> 3) {                              // uniform: only the 8 registers of the site's group are touched
+#define JPEGAMD_PUT(G)                                                                                    \
+    case G:                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) n[8 * G + j] = (j == jj && lane == fl) ? val : n[8 * G + j]; \
+        break;
+                        JPEGAMD_PUT(0) JPEGAMD_PUT(1) JPEGAMD_PUT(2) JPEGAMD_PUT(3)
+#undef JPEGAMD_PUT
+                    }
                 }
             }
         }
@@ -210,65 +335,116 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out) {
             const size_t blk = (size_t)by * im.blocks_w + bx;
             if (out.tap_zz) {
 #pragma unroll
-                for (int H = 0; H < 2; ++H)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) out.tap_zz[blk * 64 + 32 * h + 16 * H + r] = (int16_t)n[H][r];
+                for (int st = 0; st < 32; ++st) out.tap_zz[blk * 64 + 16 * (st >> 3) + 8 * h + (st & 7)] = (int16_t)n[st];
             }
             if (out.tap_mask) atomicOr((unsigned long long *)&out.tap_mask[blk], (unsigned long long)exact_mask);
         }
+        TSTAMP(5);   // exact fallback
 
-
-        // ---- 5. per-lane symbol counts -> list positions (DPP prefix sums, both halves agree per block) ----
-        int nnz = 0;
+#if JPEGAMD_TILE_PREFETCH == 2
+        // The next tile's rows are requested HERE: their 24 registers are live only across the counts and appends
+        // (and the loop head), not across the MFMA and quantiser phases where the register file is full.
+        if (nxt < grp_hi && tg_next.interior) request_rows(tg_next, raw);
+#endif
+        // ---- 5. symbol counts per (lane, group), packed one byte per group -> list positions ---------
+        // A block's list is ordered by zigzag position: group 0 of lane h=0, group 0 of lane h=1, group 1 of h=0, ...
+        const bool eob = (h == 1) && (gact[3] ? (n[31] == 0) : true);             // rle.c:121-123 (zigzag 63)
+        uint32_t cnt = (h == 0) ? 1u : 0u;                                          // the DC item
 #pragma unroll
-        for (int H = 0; H < 2; ++H)
+        for (int G = 0; G < 4; ++G) {
+            if (!gact[G]) continue;
+            uint32_t c = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nnz += (n[H][r] != 0) ? 1 : 0;
-        if (h == 0) nnz -= (n[0][0] != 0) ? 1 : 0;                                  // DC is not an AC symbol
-        const bool eob = (h == 1) && (n[1][15] == 0);                               // rle.c:121-123 (zigzag 63)
-        const uint32_t cnt = active ? (uint32_t)(nnz + (h == 0 ? 1 : (eob ? 1 : 0))) : 0u;
+            for (int j = 0; j < 8; ++j) {
+                const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];   // DC is not an AC symbol
+                c += (v != 0) ? 1u : 0u;
+            }
+            cnt += c << (8 * G);
+        }
+        cnt += eob ? (1u << 24) : 0u;
+        if (!active) cnt = 0u;
         const uint32_t partner = other_half(cnt, lane);
-        const uint32_t tb = cnt + partner;                                          // symbols of block b
+        const uint32_t tg4 = cnt + partner;                                         // per-group symbols of block b (bytes)
+        const uint32_t tb = __builtin_amdgcn_sad_u8(tg4, 0u, 0u);                   // ... and their sum
         const uint32_t incl = half_incl_scan_dpp(tb);
-        const uint32_t my_base = incl - tb + (h ? partner : 0u);
         const uint32_t t_all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+        uint32_t pre = tg4 + (tg4 << 8);
+        pre += pre << 16;                                                           // inclusive prefix over the groups, per byte
+        const uint32_t starts = (pre << 8) + (h ? partner : 0u);                    // byte G: items of the block ahead of my run G
+        const uint32_t blk_base = incl - tb;
 
         // DC prediction inside the tile (rle.c:59-70); the first block keeps its absolute value, the entropy
         // kernel subtracts the previous tile's last DC.
-        const int pred = lane_shift_up1(n[0][0]);
-        const uint32_t dc_item = (b == 0) ? (kItDc | kItFirst | (uint32_t)(n[0][0] & 0xFFFF))
-                                          : (kItDc | (uint32_t)((n[0][0] - pred) & 0xFFFF));
+        const int pred = lane_shift_up1(n[0]);
+        const uint32_t dc_item = (b == 0) ? (kItDc | kItFirst | (uint32_t)(n[0] & 0xFFFF)) : (kItDc | (uint32_t)((n[0] - pred) & 0xFFFF));
+        TSTAMP(6);   // counts + scans
 
         // ---- 6. append the items: slot 0 of the list is a zero sentinel ("previous item" of the first) ----
+        // Per stored item: one SDWA add writes the zigzag position into the upper half of the value's own register,
+        // one buffer store (32-bit offset against the tile's descriptor), one offset increment.
         uint32_t *list = out.tile_items + (size_t)tile * kTileItemCap;
+        const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list + 1, 0, (kTileItemCap - 1) * 4, 0x00020000);
         if (active) {
-            uint32_t *p = list + 1 + my_base;
-            const uint32_t zhi = (uint32_t)(32 * h) << 16;
-            if (h == 0) *p++ = dc_item;
+            uint32_t off = 0;
 #pragma unroll
-            for (int H = 0; H < 2; ++H)
+            for (int G = 0; G < 4; ++G) {
+                if (!gact[G]) continue;
+                off = (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
+                const uint32_t zg = (uint32_t)(16 * G + 8 * h);
+                if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, 0); off += 4u; }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int v = (H == 0 && r == 0 && h == 0) ? 0 : n[H][r];
-                    if (v != 0) *p++ = (zhi + ((uint32_t)(16 * H + r) << 16)) | (uint32_t)(v & 0xFFFF);
+                for (int j = 0; j < 8; ++j) {
+                    const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
+                    if (v != 0) {
+                        uint32_t item = (uint32_t)v;
+                        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                            : "+v"(item) : "v"(zg), "n"(j));
+                        __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, 0);
+                        off += 4u;
+                    }
                 }
-            if (eob) *p = 64u << 16;                                                // value 0, not DC = EOB
+            }
+            if (eob) {
+                if (!gact[3]) off = (blk_base + (starts >> 24)) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(64u << 16, lrsrc, off, 0, 0);     // value 0, not DC = EOB
+            }
         }
         if (lane == 0) {
             list[0] = 0u;
             out.tile_count[tile] = t_all;
-            out.tile_lastdc[tile] = __builtin_amdgcn_readlane(n[0][0], nblk - 1);
+            out.tile_lastdc[tile] = __builtin_amdgcn_readlane(n[0], nblk - 1);
             out.tile_exact[tile] = (uint32_t)nexact;
         }
+#undef JPEGAMD_ACC
+        TSTAMP(7);   // appends
+        tile = nxt;
+        tg = tg_next;
+        nxt = grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
     }
+    // the last wave of the group re-arms its counters for the next launch on this context
+    if (lane == 0 && atomicAdd(ctr + 1, 1u) == (uint32_t)grp_waves - 1u) {
+        ctr[0] = 0u;
+        ctr[1] = 0u;
+    }
+#ifdef JPEGAMD_STAMPS
+    if (lane == 0 && out.stamps) for (int i = 0; i < 10; ++i) out.stamps[(size_t)(blockIdx.x * kWavesT + wave) * 16 + i] = st_sum[i];
+#endif
 }
 
 int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream) {
     // persistent: at most 2 workgroups per CU (16 waves/CU at 4 waves/SIMD), fewer for small images
-    const int wgs = (im.num_tiles + kWavesT - 1) / kWavesT;
-    const dim3 grid(wgs < 512 ? wgs : 512), block(64 * kWavesT);
-    if (taps) hipLaunchKernelGGL(k_tile_transform<true>, grid, block, 0, (hipStream_t)stream, im, out);
-    else hipLaunchKernelGGL(k_tile_transform<false>, grid, block, 0, (hipStream_t)stream, im, out);
+    const int wgs_all = (im.num_tiles + kWavesT - 1) / kWavesT;
+    const int wgs = wgs_all < 512 ? wgs_all : 512;
+    TileSched sch;
+    sch.grp_shift = 0;
+    while ((2 << sch.grp_shift) <= wgs && (2 << sch.grp_shift) <= kTileGroups) ++sch.grp_shift;
+    const int groups = 1 << sch.grp_shift;
+    sch.tiles_per_group = (im.num_tiles + groups - 1) / groups;
+    const uint64_t magic = 0x100000000ull / (uint64_t)im.tiles_per_row + 1ull;
+    sch.tpr_magic = magic > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)magic;   // tiles_per_row == 1: the correction step makes up for it
+    const dim3 grid(wgs), block(64 * kWavesT);
+    if (taps) hipLaunchKernelGGL(k_tile_transform<true>, grid, block, 0, (hipStream_t)stream, im, out, sch);
+    else hipLaunchKernelGGL(k_tile_transform<false>, grid, block, 0, (hipStream_t)stream, im, out, sch);
     return (int)hipGetLastError();
 }
 

@@ -246,7 +246,7 @@ double from_bf16(uint16_t b) {
 }
 }  // namespace
 
-void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64]) {
+void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64], bool grouped) {
     std::memset(mt, 0, sizeof(*mt));
     QuantConsts qc;
     double delta_aan[64];
@@ -269,7 +269,10 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
                 term[0][p] = from_bf16(lo); term[1][p] = from_bf16(mid); term[2][p] = from_bf16(hi);
                 split_res += std::fabs(kmat[p] - (term[0][p] + term[1][p] + term[2][p]));
                 // scatter into the A-operand order: chain H, matrix row R, k-step s, lane (hk, R), element j
-                const int h = z >> 5, H = (z >> 4) & 1, r = z & 15;
+                // half-major (fused kernel): lane half h = z >> 5 holds z = 32h + 16H + r in accumulator H, register r;
+                // grouped (split pipeline): lane half h = (z >> 3) & 1 holds z = 16G + 8h + j at site 8G + j = 16H + r
+                const int site = grouped ? 8 * (z >> 4) + (z & 7) : (z & 31);
+                const int h = grouped ? (z >> 3) & 1 : z >> 5, H = site >> 4, r = site & 15;
                 const int R = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int s = p >> 4, hk = (p >> 3) & 1, j = p & 7;
                 const int lane = 32 * hk + R;
@@ -303,6 +306,19 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
     mt->bias = (float)(0.5 + dmax * 1.001 + 1.0e-7);
     const double db = (double)mt->bias - 0.5;
     for (int z = 0; z < 64; ++z) mt->qthr[z] = (float)(db + delta_z[z] * 1.001 + 1.0e-7);
+    // zero threshold of a group: qthr < fl(a * qmul + bias) < 1 (i.e. floor = 0, not flagged) for every |a| below it;
+    // the 2^-18 relative margin covers the single rounding of the kernel's fma
+    for (int g = 0; g < 4; ++g)
+        for (int h = 0; h < 2; ++h) {
+            double t = 1.0e30;
+            for (int j = 0; j < 8; ++j) {
+                const int z = 16 * g + 8 * h + j;
+                const double up = 1.0 - (double)mt->bias, dn = (double)mt->bias - (double)mt->qthr[z];
+                t = std::fmin(t, std::fmin(up, dn) / (double)mt->qmul[z]);
+            }
+            mt->grp_thr[2 * g + h] = (float)(t * (1.0 - 1.0 / 262144.0));
+            if ((double)mt->grp_thr[2 * g + h] > t * (1.0 - 1.0 / 524288.0)) mt->grp_thr[2 * g + h] = std::nextafterf(mt->grp_thr[2 * g + h], 0.0f);
+        }
 }
 
 #include "std_table_consts.inc"

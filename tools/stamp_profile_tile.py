@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-phase cycle shares of k_tile_transform from in-kernel s_memtime stamps (per wave, summed over its tiles).
+Needs a diagnostic build:  make -C jpeg-image-compression_amd EXTRA_HIPFLAGS=-DJPEGAMD_STAMPS
+The stamps do not drain vmcnt, so memory overlap is as shipped; s_memtime ticks at 100 MHz on gfx950."""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+os.environ["JPEGAMD_STAMPS"] = "1"
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "jpeg-image-compression_amd" / "python"))
+import numpy as np
+import torch
+import jpegamd
+
+w = h = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+bmp = jpegamd.synth_bmp(w, h, 1000, 0, 0)
+img, off = jpegamd.parse_bmp(bmp)
+px = torch.frombuffer(bytearray(bmp[off:off + img.row_stride * h]), dtype=torch.uint8).cuda()
+enc = jpegamd.Encoder(w, h)
+cap = 4096 + w * h
+out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+size = torch.zeros(1, dtype=torch.int64, device="cuda")
+d = jpegamd.Encoder.image(px.data_ptr(), w, h, img.row_stride, True)
+for _ in range(3):
+    enc.encode_async(d, out.data_ptr(), cap, size.data_ptr(), True, 0)
+    enc.finish()
+nwaves = min(512, (((h + 7) // 8) * (((w + 7) // 8 + 31) // 32) + 7) // 8) * 8
+buf = np.zeros((nwaves, 16), np.uint64)
+fn = jpegamd.lib.jpegamd_debug_read_stamps
+fn.restype = C.c_int32
+fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+rc = fn(enc._h, buf.ctypes.data, nwaves)
+assert rc == 0, rc
+names = ["loop/geometry", "wait rows + luma", "issue next loads", "mfma", "quantise", "exact fallback", "counts+scans", "appends"]
+tot = buf[:, :8].sum()
+print(f"waves {nwaves}, mean ticks per wave {buf[:, :8].sum(axis=1).mean():.0f} (max {buf[:, :8].sum(axis=1).max()})")
+for i, n in enumerate(names):
+    print(f"  {n:18s} {buf[:, i].mean():10.0f} ticks/wave  {100.0 * buf[:, i].sum() / tot:5.1f} %")
+tw = buf[:, :8].sum(axis=1).astype(np.float64).reshape(-1, 8)          # [workgroup][wave]
+print(f"per-wave total: mean {tw.mean():.0f}  std {tw.std():.0f}  p50 {np.percentile(tw, 50):.0f}  p90 {np.percentile(tw, 90):.0f}  p99 {np.percentile(tw, 99):.0f}  max {tw.max():.0f}")
+print(f"workgroup means: std {tw.mean(axis=1).std():.0f}  min {tw.mean(axis=1).min():.0f}  max {tw.mean(axis=1).max():.0f};  within-workgroup std (mean) {tw.std(axis=1).mean():.0f}")
+for i, n in enumerate(names):
+    col = buf[:, i].astype(np.float64)
+    print(f"  {n:18s} std {col.std():8.0f}  p99 {np.percentile(col, 99):8.0f}  max {col.max():8.0f}")
+ex = buf[:, 5].astype(np.float64)
+print("corr(total, exact) =", np.corrcoef(tw.reshape(-1), ex)[0, 1], " corr(total, appends) =", np.corrcoef(tw.reshape(-1), buf[:, 7].astype(np.float64))[0, 1])
