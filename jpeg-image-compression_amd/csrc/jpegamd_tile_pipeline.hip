@@ -379,6 +379,10 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const uint32_t dc_item = (b == 0) ? (kItDc | kItFirst | (uint32_t)(n[0] & 0xFFFF)) : (kItDc | (uint32_t)((n[0] - pred) & 0xFFFF));
         TSTAMP(6);   // counts + scans
 
+        // The ticket requested at the top of the iteration is collected here, BEFORE the item stores are issued:
+        // the wait for it then covers no younger memory operation (built with the atomic optimizer off -- its
+        // expansion reads the result back, and waits for vmcnt(0), right behind the atomic).
+        const int nxt_ticket = grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
         // ---- 6. append the items: slot 0 of the list is a zero sentinel ("previous item" of the first) ----
         // Per stored item: one SDWA add writes the zigzag position into the upper half of the value's own register,
         // one buffer store (32-bit offset against the tile's descriptor), one offset increment.
@@ -419,7 +423,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         TSTAMP(7);   // appends
         tile = nxt;
         tg = tg_next;
-        nxt = grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
+        nxt = nxt_ticket;
     }
     // the last wave of the group re-arms its counters for the next launch on this context
     if (lane == 0 && atomicAdd(ctr + 1, 1u) == (uint32_t)grp_waves - 1u) {
