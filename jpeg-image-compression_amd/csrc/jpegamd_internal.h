@@ -43,8 +43,8 @@ struct StdConsts {
 // each; lane l = (h = l >> 5, b = l & 31) ends up with 32 coefficients of block b: zigzag
 // positions 32h + 16H + r for chain H in {0,1}, accumulator register r in [0,16).
 constexpr int kTileBlocks = 32;
-constexpr int kSegTiles = 4;                         // tiles per segment (= per wavefront)
-constexpr int kSegBlocksM = kTileBlocks * kSegTiles; // 128
+constexpr int kSegTiles = 8;                         // tiles per segment (= per wavefront)
+constexpr int kSegBlocksM = kTileBlocks * kSegTiles; // 256
 constexpr int kSegCapWordsM = ((kSegBlocksM * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64;
 constexpr int kAFragWords = 3 * 2 * 4 * 64 * 4;      // [term][chain][kstep][lane] x 8 bf16 = 24 KiB
 // split pipeline (jpegamd_tile_pipeline.hip): per-tile symbol lists in HBM; slot 0 is a sentinel, 64 words of read slack
