@@ -250,6 +250,23 @@ bool saveJPEGGrayscale(const char *filename, const BMPImage *img);
 int64_t jpegamd_encode_bmp_memory(const uint8_t *bmp, uint64_t bmp_len, int32_t quality,
                                   uint8_t *out, uint64_t out_cap);
 
+/* File-to-file batch encoding with the host I/O and the PCIe transfers overlapped (no
+ * reference counterpart: natural_c/src/main.c:21-24 handles one file, synchronously).
+ * Files are processed in order with a few in flight: pinned staging buffers, one HIP stream
+ * and one encoder context per slot; a file's read/upload overlaps the encode and the
+ * download/write of its neighbours.  status[i] (optional) receives 0 or the JPEGAMD_ERR_*
+ * code of file i; a failing file does not stop the batch.  Returns 0 when every file was
+ * written, JPEGAMD_ERR_BMP when some failed, another code when nothing could run. */
+typedef struct JpegAmdBatchStats {
+    int32_t files_ok, files_failed;
+    uint64_t bytes_in, bytes_out;       /* BMP file bytes read / JFIF bytes written (files_ok only) */
+    double seconds_total;               /* wall time of the call */
+    double seconds_read, seconds_write; /* host time spent inside fread / fwrite */
+} JpegAmdBatchStats;
+int32_t jpegamd_encode_files(const char *const *in_paths, const char *const *out_paths,
+                             int32_t count, int32_t quality, int32_t *status,
+                             JpegAmdBatchStats *stats);
+
 /* Parse a BMP header the way loadBMPImage does (bmp_handler.c:22-88); fills a JpegAmdImage
  * whose `pixels` is an OFFSET into the file (cast to pointer), for callers that upload the
  * file themselves.  Returns 0 or JPEGAMD_ERR_BMP. */

@@ -97,7 +97,7 @@ EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_byt
             "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
             "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts jpegamd_debug_mfma_consts JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
-            "jpegamd_encode_bmp_memory jpegamd_parse_bmp").split()
+            "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files").split()
 
 
 def quant_consts(quality: int = 50):
@@ -166,6 +166,27 @@ def encode_bmp_bytes(bmp: bytes, quality: int = 0) -> bytes:
             raise JpegAmdError(int(n), "jpegamd_encode_bmp_memory")
         return bytes(out[:n])
     raise JpegAmdError(-8, "jpegamd_encode_bmp_memory")
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("files_ok", C.c_int32), ("files_failed", C.c_int32), ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64),
+                ("seconds_total", C.c_double), ("seconds_read", C.c_double), ("seconds_write", C.c_double)]
+
+
+def encode_files(in_paths, out_paths, quality: int = 0):
+    """File-to-file batch with overlapped I/O and transfers (jpegamd_encode_files) -> (return code, [status per file], BatchStats)."""
+    n = len(in_paths)
+    if len(out_paths) != n:
+        raise ValueError("in_paths and out_paths differ in length")
+    ins = (C.c_char_p * n)(*[str(p).encode() for p in in_paths])
+    outs = (C.c_char_p * n)(*[str(p).encode() for p in out_paths])
+    status = (C.c_int32 * n)()
+    st = BatchStats()
+    fn = lib.jpegamd_encode_files
+    fn.restype = C.c_int32
+    fn.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(BatchStats)]
+    rc = fn(ins, outs, n, quality, status, C.byref(st))
+    return int(rc), list(status), st
 
 
 class Encoder:

@@ -241,3 +241,35 @@ def test_decodes_with_an_independent_decoder(jpegamd, dev):
     src = PIL.open(io.BytesIO(bmp)).convert("L")
     mse = float(np.mean((np.asarray(im, np.float64) - np.asarray(src, np.float64)) ** 2))
     assert mse < 60.0, mse
+
+
+@pytest.mark.gpu
+def test_file_batch_pipeline_matches_oracle(jpegamd, oracle, dev, tmp_path):
+    """jpegamd_encode_files: several files of different geometry in flight at once, one bad input in the middle;
+    every written stream equals the oracle's, the bad file reports its own error and does not stop the batch."""
+    cases = [(640, 480, 11, 0, 0), (203, 117, 5, 1, 0), (1024, 768, 3, 0, 0), (64, 64, 1, 2, 0), (333, 250, 4, 0, 1), (1920, 1080, 9, 0, 0), (8, 8, 2, 1, 0)]
+    ins, outs, bmps = [], [], []
+    for i, (w, h, seed, kind, flags) in enumerate(cases):
+        bmp = jpegamd.synth_bmp(w, h, seed, kind, flags)
+        p = tmp_path / f"in_{i}.bmp"
+        p.write_bytes(bmp)
+        ins.append(p); outs.append(tmp_path / f"out_{i}.jpg"); bmps.append(bmp)
+    bad = tmp_path / "bad.bmp"
+    bad.write_bytes(b"BM" + bytes(40))
+    ins.insert(3, bad); outs.insert(3, tmp_path / "bad.jpg"); bmps.insert(3, None)
+    rc, status, st = jpegamd.encode_files(ins, outs)
+    assert rc == -7
+    assert status[3] == -7 and not (tmp_path / "bad.jpg").exists()
+    assert st.files_ok == len(cases) and st.files_failed == 1
+    total = 0
+    for i, bmp in enumerate(bmps):
+        if bmp is None:
+            continue
+        assert status[i] == 0
+        got = outs[i].read_bytes()
+        assert got == oracle.encode_bmp(bmp), f"file {i}"
+        total += len(got)
+    assert st.bytes_out == total and st.seconds_total > 0
+    # all files readable -> return code 0
+    rc2, status2, st2 = jpegamd.encode_files(ins[:3], outs[:3])
+    assert rc2 == 0 and status2 == [0, 0, 0] and st2.files_failed == 0
