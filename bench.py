@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams (one encoder context each) the steps alternate over; >1 lets the latency-bound tail "
                          "kernels of one image overlap the transform kernel of the next")
+    ap.add_argument("--force-gather", action="store_true", help="run the N > 1 gather path with a one-rank group (rehearsal on one GPU)")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: images per rank carried by one gather to rank 0 (few, large collectives)")
     ap.add_argument("--cpu-sample-rows", type=int, default=2048,
                     help="rows of the step-0 image the CPU baseline encodes (bounded sample)")
     return ap.parse_args()
@@ -141,10 +144,14 @@ def main():
         return 2
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:                                   # rehearsal of the N > 1 exchange path with a one-rank RCCL group
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w, h, K, W = args.width, args.height, args.steps, args.warmup
     inputs, stride, first_bmp = make_inputs(args, rank, torch, jpegamd)
@@ -158,29 +165,56 @@ def main():
     imgs = [jpegamd.Encoder.image(t.data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, args.quality) for t in inputs]
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
 
+    # N > 1: the finished bitstreams are collected at rank 0, `gather_every` images per collective (few, large
+    # messages: each peer's records cross its own xGMI link to the root in one piece).  The record size is fixed
+    # before the timed region from the sizes the rotating inputs actually produce (+5 %), agreed over all ranks.
     gather = None
-    if world > 1:
-        from jpegamd.sharding import StreamGather
-        gather = StreamGather(cap, torch.device("cuda", local_rank), dst=0, depth=nbuf)
+    G = max(1, args.gather_every)
+    if dist is not None:
+        from jpegamd.sharding import BatchedStreamGather
+        biggest = 0
+        for im in imgs:
+            encs[0].encode_async(im, outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
+            biggest = max(biggest, int(encs[0].finish().jfif_bytes))
+        t = torch.tensor([biggest], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        slot_bytes = ((int(t.item()) * 21 // 20 + 4096 + 255) // 256) * 256 + 8
+        gather = BatchedStreamGather(slot_bytes, G, torch.device("cuda", local_rank), dst=0, depth=2)
+        rec_ptrs = {}
+        for st_i in range(2 * G):
+            pl, sz = gather.record(st_i)
+            rec_ptrs[st_i] = (pl.data_ptr(), pl.numel(), sz.data_ptr())
     pending = [None] * nbuf
+    last_step = [-1]
 
     def step(i):
-        b = i % nbuf
         si = i % nstreams                                         # steps alternate over the streams / contexts
         with torch.cuda.stream(tstreams[si]):
-            if pending[b] is not None:                            # the gather that read outs[b] nbuf steps ago
-                pending[b].wait()
-                pending[b] = None
-            encs[si].encode_async(imgs[i % ROTATE], outs[b].data_ptr(), cap, sizes[b].data_ptr(), True,
-                                  tstreams[si].cuda_stream)
-            if gather is not None:
-                pending[b] = gather.start(outs[b], sizes[b], b)
+            if gather is None:
+                b = i % nbuf
+                encs[si].encode_async(imgs[i % ROTATE], outs[b].data_ptr(), cap, sizes[b].data_ptr(), True,
+                                      tstreams[si].cuda_stream)
+            else:
+                gather.reserve(i)                                 # the collective that last read this buffer
+                optr, ocap, sptr = rec_ptrs[i % (2 * G)]
+                encs[si].encode_async(imgs[i % ROTATE], optr, ocap, sptr, True, tstreams[si].cuda_stream)
+                if i % G == G - 1:
+                    commit(i, False)
+        last_step[0] = i
+
+    def commit(i, force):
+        cur = torch.cuda.current_stream()
+        for sj in tstreams:                                       # the buffer's records were produced on all streams
+            if sj != cur:
+                cur.wait_event(sj.record_event())
+        gather.commit(i, force=force)
 
     def drain():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        if gather is not None and last_step[0] >= 0:
+            if last_step[0] % G != G - 1:
+                with torch.cuda.stream(tstreams[0]):
+                    commit(last_step[0], True)
+            gather.wait_all()
         torch.cuda.synchronize()
 
     for i in range(W):
@@ -242,8 +276,8 @@ def main():
         roof_note = "timed region (single stream)"
 
     # parity spot check of the last output against the committed natural_c golden (when present)
-    out_bytes = bytes(outs[last % nbuf][: int(sizes[last % nbuf].item())].cpu().numpy()) if nstreams == 1 else None
-    if out_bytes is None:                                          # the extra pass above reused outs[0]: re-encode `last`
+    out_bytes = bytes(outs[last % nbuf][: int(sizes[last % nbuf].item())].cpu().numpy()) if (nstreams == 1 and gather is None) else None
+    if out_bytes is None:                                          # outs[] was reused (extra pass) or bypassed (gather records): re-encode `last`
         encs[0].encode_async(imgs[last % ROTATE], outs[1].data_ptr(), cap, sizes[1].data_ptr(), True, tstreams[0].cuda_stream)
         encs[0].finish()
         out_bytes = bytes(outs[1][: int(sizes[1].item())].cpu().numpy())
@@ -257,8 +291,9 @@ def main():
             parity = "sha256 == natural_c golden" if ok else "MISMATCH vs natural_c golden"
 
     if gather is not None and rank == 0:
-        streams = gather.result((W + K - 1) % nbuf)
-        if len(streams) != world or any(s[:2] != b"\xff\xd8" or s[-2:] != b"\xff\xd9" for s in streams):
+        per_rank = gather.result(W + K - 1)
+        used = (W + K - 1) % G + 1 if (W + K) % G else G
+        if len(per_rank) != world or any(s[:2] != b"\xff\xd8" or s[-2:] != b"\xff\xd9" for r in per_rank for s in r[:used]):
             raise RuntimeError("gathered streams are not complete JFIF files")
 
     if rank != 0:

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         if (t < 32) s_huff[256 + t] = t < 16 ? a.huff[256 + t] : 0u;
     }
     __syncthreads();
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int seg = (int)blockIdx.x * kWavesE + wave;
     if (seg >= a.num_segs) return;
     uint32_t *win = s_win[wave];

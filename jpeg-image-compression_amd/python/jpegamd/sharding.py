@@ -84,3 +84,77 @@ class StreamGather:
                 raise RuntimeError(f"gathered size {n} outside capacity {self.capacity}")
             out.append(bytes(p[:n].cpu().numpy()))
         return out
+
+
+class BatchedStreamGather:
+    """Few, large collectives: `slots` consecutive results of a rank travel in ONE gather.
+
+    Each rank owns `depth` staging buffers of `slots` fixed-size records.  A record is `slot_bytes` long: the
+    bitstream at offset 0 and its byte count (int64) in the last 8 bytes, so the encoder writes both straight into
+    the staging buffer (`record(step)` gives the two tensors to point it at) and one collective moves payloads and
+    sizes together.  `commit(step)` starts the asynchronous gather of a buffer when its last record was produced;
+    `reserve(step)` makes the calling stream wait for the gather that last read the buffer `step` is about to
+    overwrite.  Sized for xGMI: at 8 ranks the root receives 7 x slots x slot_bytes per collective, each peer
+    over its own link, instead of one small padded message per image.
+    """
+
+    def __init__(self, slot_bytes: int, slots: int, device, group=None, dst: int = 0, depth: int = 2):
+        if slot_bytes % 8 or slot_bytes < 16:
+            raise ValueError("slot_bytes must be a multiple of 8 (the size field is an aligned int64)")
+        self.group, self.dst, self.slot_bytes, self.slots, self.depth = group, dst, int(slot_bytes), int(slots), int(depth)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.is_dst = self.rank == dst
+        n = self.slot_bytes * self.slots
+        self._stage = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self._recv = [[torch.empty(n, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.is_dst else None
+                      for _ in range(depth)]
+        self._work = [None] * depth
+        self.collectives = 0
+
+    def _where(self, step: int) -> Tuple[int, int]:
+        return (step // self.slots) % self.depth, step % self.slots
+
+    def record(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(payload uint8[slot_bytes - 8], size int64[1]) views of the record `step` writes into."""
+        b, k = self._where(step)
+        rec = self._stage[b][k * self.slot_bytes:(k + 1) * self.slot_bytes]
+        return rec[:self.slot_bytes - 8], rec[self.slot_bytes - 8:].view(torch.int64)
+
+    def reserve(self, step: int) -> None:
+        """Order the current stream after the collective that last read the buffer of `step` (no-op if none)."""
+        b, _ = self._where(step)
+        if self._work[b] is not None:
+            self._work[b].wait()
+
+    def commit(self, step: int, force: bool = False):
+        """After record `step` was produced on the current stream: start the gather if the buffer is complete."""
+        b, k = self._where(step)
+        if k != self.slots - 1 and not force:
+            return None
+        self._work[b] = dist.gather(self._stage[b], self._recv[b], dst=self.dst, group=self.group, async_op=True)
+        self.collectives += 1
+        return self._work[b]
+
+    def wait_all(self) -> None:
+        for w in self._work:
+            if w is not None:
+                w.wait()
+
+    def result(self, step: int) -> List[List[bytes]]:
+        """On dst, after wait_all() and a device synchronise: per rank, the streams of the buffer holding `step`."""
+        if not self.is_dst:
+            return []
+        b, _ = self._where(step)
+        out = []
+        for r in range(self.world):
+            buf = self._recv[b][r].cpu()
+            streams = []
+            for k in range(self.slots):
+                rec = buf[k * self.slot_bytes:(k + 1) * self.slot_bytes]
+                n = int(rec[self.slot_bytes - 8:].view(torch.int64).item())
+                if n < 0 or n > self.slot_bytes - 8:
+                    raise RuntimeError(f"gathered size {n} outside the record ({self.slot_bytes - 8})")
+                streams.append(bytes(rec[:n].numpy()))
+            out.append(streams)
+        return out

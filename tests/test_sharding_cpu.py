@@ -82,3 +82,46 @@ def test_two_rank_gloo_gather_of_bitstreams():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_images, ret), nprocs=world, join=True)
     assert ret.get("ok") is True and ret.get("n") == n_images
+
+
+def _batched_worker(rank: int, world: int, port: int, ret):
+    for p in (str(PKG / "python"), str(ROOT)):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import jpegamd
+    from jpegamd.sharding import BatchedStreamGather
+    from oracle import oracle
+    slots, steps = 3, 9                                   # three full buffers through a depth-2 ring
+    g = BatchedStreamGather(2048, slots, torch.device("cpu"), dst=0, depth=2)
+    ok = True
+    for s in range(steps):
+        g.reserve(s)
+        payload, size = g.record(s)
+        jf = oracle.encode_bmp(jpegamd.synth_bmp(16 + s, 8 + 8 * rank, 7 * rank + s, 0, 0))
+        payload[:len(jf)] = torch.frombuffer(bytearray(jf), dtype=torch.uint8)
+        size[0] = len(jf)
+        started = g.commit(s)
+        assert (started is not None) == (s % slots == slots - 1)
+        if started is not None:
+            g.wait_all()
+            if rank == 0:
+                res = g.result(s)
+                for r in range(world):
+                    for k in range(slots):
+                        step = s - slots + 1 + k
+                        ok &= res[r][k] == oracle.encode_bmp(jpegamd.synth_bmp(16 + step, 8 + 8 * r, 7 * r + step, 0, 0))
+    if rank == 0:
+        ret["ok"] = bool(ok)
+        ret["collectives"] = g.collectives
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_batched_gather():
+    """bench.py's N > 1 exchange: several images per collective, sizes carried inside the records."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_batched_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret.get("ok") is True and ret.get("collectives") == 3
