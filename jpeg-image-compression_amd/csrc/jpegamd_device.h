@@ -149,6 +149,13 @@ __device__ __forceinline__ int floor_to_int(float x) {
     return r;
 }
 
+// bits = 2 * bits + (g <= thr): compare + add-with-carry, 2 instructions (hipcc's own sequence is compare, select,
+// shift, or -- plus hazard nops).  g comes from an ordinary VALU op.
+__device__ __forceinline__ uint32_t shift_in_le(uint32_t bits, float g, float thr) {
+    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(g), "v"(thr) : "vcc");
+    return bits;
+}
+
 __device__ __forceinline__ float exact_coef_float(float pixel /*lane j: p[x=j>>3][y=j&7]*/, int u, int v,
                                                   const float *s_cos, int lane) {
     const float cx = s_cos[u * 8 + (lane >> 3)];     // COS_LUT[x][u]

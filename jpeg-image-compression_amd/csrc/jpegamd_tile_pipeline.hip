@@ -233,8 +233,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 
         // ---- 2. the 64x64 transform on the matrix pipe: small terms first ----------------------
         f32x16 acc[2];
-#pragma unroll 1
-        for (int t = 0; t < 3; ++t) {          // rolled; the A fragments of one term are fetched kAfrBatch at a time so that
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {          // unrolled (a rolled loop paid ~12 scalar/branch slots per term for the C = 0 special case);
+                                               // the A fragments of one term are fetched kAfrBatch at a time so that
             const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];     // the MFMAs issue back to back behind ONE wait
 #pragma unroll
             for (int s0 = 0; s0 < 4; s0 += kAfrBatch) {
@@ -288,7 +289,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     const float2 q = sq_lane[16 * G + j];
                     const float zc = fmaf(JPEGAMD_ACC(st), q.x, bias);      // z + 0.5 + delta
                     n[st] = floor_to_int(zc);
-                    gb = gb + gb + ((__builtin_amdgcn_fractf(zc) <= q.y) ? 1u : 0u);   // one v_addc: within delta of a tie
+                    gb = shift_in_le(gb, __builtin_amdgcn_fractf(zc), q.y);            // within delta of a tie
                 }
                 flagbits |= gb << (8 * G);
             } else if (kTaps) {
