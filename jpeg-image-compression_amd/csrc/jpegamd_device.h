@@ -149,11 +149,41 @@ __device__ __forceinline__ int floor_to_int(float x) {
     return r;
 }
 
-// bits = 2 * bits + (g <= thr): compare + add-with-carry, 2 instructions (hipcc's own sequence is compare, select,
-// shift, or -- plus hazard nops).  g comes from an ordinary VALU op.
-__device__ __forceinline__ uint32_t shift_in_le(uint32_t bits, float g, float thr) {
-    asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(g), "v"(thr) : "vcc");
+// Eight predicates folded into a register with 2 instructions each and no hazard padding: a compare writes a lane
+// mask, an add-with-carry consumes it.  gfx950 needs 2 wait states between a VALU writing a lane mask and a VALU
+// reading it (hipcc pads its own compare/select pairs with s_nop -- 3 issue slots per site); here three mask
+// registers rotate so that two independent instructions always sit between a compare and its consumer.
+//   shift_in_le8: bits = (bits << 8) | sum_j (g[j] <= t[j]) << j        (sites consumed 7 .. 0)
+//   count_ne8   : c += number of non-zero v[j]
+#define JPEGAMD_FOLD8(CMP, ADD, X7, X6, X5, X4, X3, X2, X1, X0)                                                   \
+    CMP("%[A]", X7) CMP("%[B]", X6) CMP("vcc", X5) ADD("%[A]") CMP("%[A]", X4) ADD("%[B]") CMP("%[B]", X3) ADD("vcc") \
+    CMP("vcc", X2) ADD("%[A]") CMP("%[A]", X1) ADD("%[B]") CMP("%[B]", X0) ADD("vcc") ADD("%[A]") ADD("%[B]")
+
+__device__ __forceinline__ uint32_t shift_in_le8(uint32_t bits, const float (&g)[8], const float (&t)[8]) {
+    unsigned long long ma, mb;
+#define JPEGAMD_CMP(M, J) "v_cmp_le_f32 " M ", %[g" #J "], %[t" #J "]\n\t"
+#define JPEGAMD_ADD(M) "v_addc_co_u32 %[b], " M ", %[b], %[b], " M "\n\t"
+    asm(JPEGAMD_FOLD8(JPEGAMD_CMP, JPEGAMD_ADD, 7, 6, 5, 4, 3, 2, 1, 0)
+        : [b] "+v"(bits), [A] "=&s"(ma), [B] "=&s"(mb)
+        : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]),
+          [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3]), [t4] "v"(t[4]), [t5] "v"(t[5]), [t6] "v"(t[6]), [t7] "v"(t[7])
+        : "vcc");
+#undef JPEGAMD_CMP
+#undef JPEGAMD_ADD
     return bits;
+}
+
+__device__ __forceinline__ uint32_t count_ne8(uint32_t c, const int (&v)[8]) {
+    unsigned long long ma, mb;
+#define JPEGAMD_CMP(M, J) "v_cmp_ne_u32 " M ", 0, %[v" #J "]\n\t"
+#define JPEGAMD_ADD(M) "v_addc_co_u32 %[c], " M ", %[c], 0, " M "\n\t"
+    asm(JPEGAMD_FOLD8(JPEGAMD_CMP, JPEGAMD_ADD, 7, 6, 5, 4, 3, 2, 1, 0)
+        : [c] "+v"(c), [A] "=&s"(ma), [B] "=&s"(mb)
+        : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7])
+        : "vcc");
+#undef JPEGAMD_CMP
+#undef JPEGAMD_ADD
+    return c;
 }
 
 __device__ __forceinline__ float exact_coef_float(float pixel /*lane j: p[x=j>>3][y=j&7]*/, int u, int v,

@@ -282,16 +282,17 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 gact[G] = __ballot(m >= s_grp[2 * G + h]) != 0ull;
             }
             if (gact[G]) {
-                uint32_t gb = 0;
+                float fr[8], th[8];
 #pragma unroll
-                for (int j = 7; j >= 0; --j) {                      // descending: the carry shift-in leaves site j at bit j
+                for (int j = 0; j < 8; ++j) {
                     const int st = 8 * G + j;
                     const float2 q = sq_lane[16 * G + j];
                     const float zc = fmaf(JPEGAMD_ACC(st), q.x, bias);      // z + 0.5 + delta
                     n[st] = floor_to_int(zc);
-                    gb = shift_in_le(gb, __builtin_amdgcn_fractf(zc), q.y);            // within delta of a tie
+                    fr[j] = __builtin_amdgcn_fractf(zc);
+                    th[j] = q.y;
                 }
-                flagbits |= gb << (8 * G);
+                flagbits |= shift_in_le8(0u, fr, th) << (8 * G);            // bit j: site 8G + j is within delta of a tie
             } else if (kTaps) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) n[8 * G + j] = 0;
@@ -364,12 +365,10 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
             if (!gact[G]) continue;
-            uint32_t c = 0;
+            int vv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];   // DC is not an AC symbol
-                c += (v != 0) ? 1u : 0u;
-            }
+            for (int j = 0; j < 8; ++j) vv[j] = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];   // DC is not an AC symbol
+            const uint32_t c = count_ne8(0u, vv);
             cnt += c << (8 * G);
         }
         cnt += eob ? (1u << 24) : 0u;
