@@ -8,20 +8,27 @@
 //                                                         no flip, no channel swap: those are addressing modes of the kernel)
 //     enqueues H2D of the pixel rows, the encode, and the D2H of the 8-byte size
 // and then drains the slot of file i - (kSlots - 1): waits for its size, enqueues the D2H of exactly that many bytes,
-// waits, writes the .jpg.  While the host sits in fread / fwrite of one file the GPU works on the others.
+// waits, writes the .jpg.  The reads themselves run on kReaders background threads (a single thread's fread into
+// pinned memory tops out near 5 GB/s, far below PCIe): reader t fills the slots of files t, t + kReaders, ... as
+// soon as the slot's previous upload has left its pinned buffer.
 // Host code only; every byte of the stream is produced by the same device path as jpegamd_encode_async.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "jpeg_compression.h"
 
 namespace {
 
-constexpr int kSlots = 3;
+constexpr int kSlots = 4;
+constexpr int kReaders = 2;
 
 struct Slot {
     JpegAmdEncoder *enc = nullptr;
@@ -34,18 +41,30 @@ struct Slot {
     int file = -1;                  // index of the file in flight, -1 = idle
     int32_t status = 0;
     uint64_t in_bytes = 0;
+    // hand-over between the reader thread and the submitting thread
+    hipEvent_t h2d_done = nullptr;  // the upload has left h_in
+    std::mutex mu;
+    std::condition_variable cv;
+    int staged = -1;                // file whose bytes are complete in h_in (-1: none / consumed)
+    int next_file = 0, stride = 1;  // the slot takes files next_file, next_file + stride, ... strictly in that order
+    int32_t staged_rc = 0;          // read error of that file
+    size_t staged_len = 0;
+    bool h2d_pending = false;       // an upload from h_in was enqueued and not yet known to be finished
 
     void release() {
         if (enc) jpegamd_encoder_destroy(enc);
         if (stream) hipStreamDestroy(stream);
         if (size_ready) hipEventDestroy(size_ready);
+        if (h2d_done) hipEventDestroy(h2d_done);
         if (h_in) hipHostFree(h_in);
         if (h_out) hipHostFree(h_out);
         if (h_size) hipHostFree(h_size);
         if (d_in) hipFree(d_in);
         if (d_out) hipFree(d_out);
         if (d_size) hipFree(d_size);
-        *this = Slot();
+        enc = nullptr; stream = nullptr; size_ready = h2d_done = nullptr;
+        h_in = d_in = d_out = h_out = nullptr; d_size = h_size = nullptr;
+        in_cap = out_cap = 0; file = -1;
     }
     bool grow_in(size_t n) {
         if (n <= in_cap) return true;
@@ -71,45 +90,79 @@ struct Slot {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// read, parse and enqueue one file on `s`; returns 0 or a JPEGAMD_ERR_* code (the slot stays idle on error)
-int32_t submit(Slot &s, const char *path, int32_t quality, double *t_read) {
+// background: bring `path` into the slot's pinned buffer (grown on demand: only this thread touches h_in / d_in sizes
+// while the slot is not staged, and the submitting thread only reads them while it is)
+void stage_file(Slot &s, int index, const char *path, std::atomic<long long> *read_ns) {
+    {   // the previous upload from this buffer must be through
+        std::unique_lock<std::mutex> lk(s.mu);
+        s.cv.wait(lk, [&] { return s.staged < 0 && s.next_file == index; });   // readers of one slot may arrive out of order
+        if (s.h2d_pending) { hipEventSynchronize(s.h2d_done); s.h2d_pending = false; }
+    }
     const double t0 = now_s();
+    int32_t rc = JPEGAMD_OK;
+    size_t got = 0;
     FILE *fp = path ? std::fopen(path, "rb") : nullptr;
-    if (!fp) return JPEGAMD_ERR_BMP;
-    std::fseek(fp, 0, SEEK_END);
-    const long len = std::ftell(fp);
-    std::fseek(fp, 0, SEEK_SET);
-    if (len <= 0 || !s.grow_in((size_t)len)) { std::fclose(fp); return len <= 0 ? JPEGAMD_ERR_BMP : JPEGAMD_ERR_HIP; }
-    const size_t got = std::fread(s.h_in, 1, (size_t)len, fp);
-    std::fclose(fp);
-    *t_read += now_s() - t0;
+    if (!fp) {
+        rc = JPEGAMD_ERR_BMP;
+    } else {
+        std::fseek(fp, 0, SEEK_END);
+        const long len = std::ftell(fp);
+        std::fseek(fp, 0, SEEK_SET);
+        if (len <= 0) rc = JPEGAMD_ERR_BMP;
+        else if (!s.grow_in((size_t)len)) rc = JPEGAMD_ERR_HIP;
+        else got = std::fread(s.h_in, 1, (size_t)len, fp);
+        std::fclose(fp);
+    }
+    read_ns->fetch_add((long long)((now_s() - t0) * 1e9));
+    std::lock_guard<std::mutex> lk(s.mu);
+    s.staged = index; s.staged_rc = rc; s.staged_len = got;
+    s.cv.notify_all();
+}
 
+// parse and enqueue the staged file of `s`; returns 0 or a JPEGAMD_ERR_* code (the slot stays idle on error)
+int32_t submit(Slot &s, int index, int32_t quality) {
+    size_t got;
+    {
+        std::unique_lock<std::mutex> lk(s.mu);
+        s.cv.wait(lk, [&] { return s.staged == index; });
+        if (s.staged_rc) { const int32_t rc = s.staged_rc; s.staged = -1; s.next_file += s.stride; s.cv.notify_all(); return rc; }
+        got = s.staged_len;
+    }
+    const auto give_back = [&](int32_t rc, bool uploading) {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.h2d_pending = uploading;
+        s.staged = -1;
+        s.next_file += s.stride;
+        s.cv.notify_all();
+        return rc;
+    };
     JpegAmdImage img;
     uint64_t off = 0;
     int32_t rc = jpegamd_parse_bmp(s.h_in, got, &img, &off);
-    if (rc) return rc;
+    if (rc) return give_back(rc, false);
     if (!s.enc || img.width > s.enc_w || img.height > s.enc_h) {        // contexts are sized for the largest image seen
         if (s.enc) jpegamd_encoder_destroy(s.enc);
         s.enc = nullptr;
         const int32_t w = img.width > s.enc_w ? img.width : s.enc_w, h = img.height > s.enc_h ? img.height : s.enc_h;
         rc = jpegamd_encoder_create(&s.enc, w, h);
-        if (rc) return rc;
+        if (rc) return give_back(rc, false);
         s.enc_w = w; s.enc_h = h;
     }
     const size_t bytes = (size_t)img.row_stride * (size_t)img.height;
     const uint64_t cap = jpegamd_max_jfif_bytes(img.width, img.height);
     // the output buffer is sized for typical content (1 byte per pixel + container); the encoder reports -8 beyond it
     const size_t out_cap = (size_t)img.width * (size_t)img.height + 4096 < cap ? (size_t)img.width * (size_t)img.height + 4096 : (size_t)cap;
-    if (!s.grow_out(out_cap)) return JPEGAMD_ERR_HIP;
-    if (hipMemcpyAsync(s.d_in, s.h_in + off, bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess) return JPEGAMD_ERR_HIP;
+    if (!s.grow_out(out_cap)) return give_back(JPEGAMD_ERR_HIP, false);
+    if (hipMemcpyAsync(s.d_in, s.h_in + off, bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess) return give_back(JPEGAMD_ERR_HIP, false);
+    if (hipEventRecord(s.h2d_done, s.stream) != hipSuccess) { hipStreamSynchronize(s.stream); return give_back(JPEGAMD_ERR_HIP, false); }
+    s.in_bytes = (uint64_t)got;
     img.pixels = s.d_in;
     img.quality = quality;
     rc = jpegamd_encode_async(s.enc, &img, s.d_out, s.out_cap, s.d_size, 1, (void *)s.stream);
-    if (rc) return rc;
-    if (hipMemcpyAsync(s.h_size, s.d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream) != hipSuccess) return JPEGAMD_ERR_HIP;
-    if (hipEventRecord(s.size_ready, s.stream) != hipSuccess) return JPEGAMD_ERR_HIP;
-    s.in_bytes = (uint64_t)len;
-    return JPEGAMD_OK;
+    if (rc) return give_back(rc, true);
+    if (hipMemcpyAsync(s.h_size, s.d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream) != hipSuccess) return give_back(JPEGAMD_ERR_HIP, true);
+    if (hipEventRecord(s.size_ready, s.stream) != hipSuccess) return give_back(JPEGAMD_ERR_HIP, true);
+    return give_back(JPEGAMD_OK, true);
 }
 
 // wait for the slot's stream, fetch exactly the produced bytes, write the file
@@ -144,9 +197,11 @@ extern "C" int32_t jpegamd_encode_files(const char *const *in_paths, const char 
     const double t_begin = now_s();
     std::vector<Slot> slots((size_t)(count < kSlots ? (count > 0 ? count : 1) : kSlots));
     int32_t fatal = JPEGAMD_OK;
+    for (size_t k = 0; k < slots.size(); ++k) { slots[k].next_file = (int)k; slots[k].stride = (int)slots.size(); }
     for (Slot &s : slots) {
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.size_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming) != hipSuccess ||
             hipMalloc((void **)&s.d_size, sizeof(uint64_t)) != hipSuccess ||
             hipHostMalloc((void **)&s.h_size, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { fatal = JPEGAMD_ERR_HIP; break; }
     }
@@ -160,14 +215,26 @@ extern "C" int32_t jpegamd_encode_files(const char *const *in_paths, const char 
         s.file = -1;
     };
     if (!fatal) {
+        std::atomic<long long> read_ns{0};
+        int dev = 0;
+        hipGetDevice(&dev);
+        std::vector<std::thread> readers;
+        const int nreaders = count < kReaders ? count : kReaders;
+        for (int t = 0; t < nreaders; ++t)
+            readers.emplace_back([&, t] {
+                hipSetDevice(dev);
+                for (int i = t; i < count; i += nreaders) stage_file(slots[(size_t)i % slots.size()], i, in_paths[i], &read_ns);
+            });
         for (int i = 0; i < count; ++i) {
             Slot &s = slots[(size_t)i % slots.size()];
             finish_slot(s);                                        // the slot's previous file (i - slots) must be out first
-            const int32_t rc = submit(s, in_paths[i], quality, &bs.seconds_read);
+            const int32_t rc = submit(s, i, quality);
             if (rc) { if (status) status[i] = rc; ++failed; continue; }
             s.file = i;
         }
         for (size_t k = 0; k < slots.size(); ++k) finish_slot(slots[((size_t)count + k) % slots.size()]);   // oldest first
+        for (std::thread &t : readers) t.join();
+        bs.seconds_read = (double)read_ns.load() * 1e-9;
     }
     for (Slot &s : slots) s.release();
     bs.seconds_total = now_s() - t_begin;
