@@ -195,4 +195,29 @@ __device__ __forceinline__ float exact_coef_float(float pixel /*lane j: p[x=j>>3
     return __fmul_rn(ref_scale(u, v), s);                            // dct.c:93
 }
 
+// The same ordered sum through LDS: every lane publishes its term, then EVERY lane adds the 64 terms in order
+// (broadcast reads, 63 dependent v_add_f32 with hardware forwarding).  ~90 issue slots; the DPP chain above is a
+// rolled loop of ~6 slots per step (DPP needs wait states behind the add that feeds it) -- ~380 slots per event,
+// which at 12 k events per 8192^2 image was 12 % of the whole pipeline's instructions.
+__device__ __forceinline__ float exact_term_sum_lds(float t, float *terms /*LDS, 64 floats owned by this wave*/, int lane) {
+    terms[lane] = t;
+    float s = 0.0f;                                                  // dct.c:68
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 a = *reinterpret_cast<const float4 *>(&terms[8 * c]);
+        const float4 b = *reinterpret_cast<const float4 *>(&terms[8 * c + 4]);
+        s = __fadd_rn(s, a.x); s = __fadd_rn(s, a.y); s = __fadd_rn(s, a.z); s = __fadd_rn(s, a.w);
+        s = __fadd_rn(s, b.x); s = __fadd_rn(s, b.y); s = __fadd_rn(s, b.z); s = __fadd_rn(s, b.w);
+    }
+    return s;
+}
+
+__device__ __forceinline__ float exact_coef_float_lds(float pixel /*lane j: p[x=j>>3][y=j&7]*/, int u, int v, const float *s_cos,
+                                                      float *terms, int lane) {
+    const float cx = s_cos[u * 8 + (lane >> 3)];     // COS_LUT[x][u]
+    const float cy = s_cos[v * 8 + (lane & 7)];      // COS_LUT[y][v]
+    const float t = __fmul_rn(__fmul_rn(pixel, cx), cy);             // dct.c:84
+    return __fmul_rn(ref_scale(u, v), exact_term_sum_lds(t, terms, lane));   // dct.c:93
+}
+
 }  // namespace jpegamd

@@ -105,6 +105,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     __shared__ float2 s_q[64];                 // (multiplier, threshold) by zigzag position
     __shared__ float s_qstep[64];
     __shared__ float s_cos[64];
+    __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][64];   // exact-order path: the 64 terms of one coefficient
     __shared__ float s_grp[8];                 // [group][h]: |acc| below this => every site of the group quantises to an unflagged 0
     // The tile's centred luma (bf16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
     // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
@@ -327,7 +328,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     const int k = kZZ[z], u = k >> 3, v = k & 7;
                     const uint32_t pw = s_pix[wave][(lane >> 3) * 132 + (fl & 31) * 4 + ((lane & 7) >> 1)];
                     const float pix = __builtin_bit_cast(float, (lane & 1) ? (pw & 0xFFFF0000u) : (pw << 16));   // bf16 -> f32
-                    const float coef = exact_coef_float(pix, u, v, s_cos, lane);
+                    const float coef = exact_coef_float_lds(pix, u, v, s_cos, s_terms[wave], lane);
                     const int val = ref_quantise(coef, s_qstep[z]);
                     ++nexact;
                     if (kTaps && lane == fl) exact_mask |= 1ull << k;
