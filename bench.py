@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--kind", type=int, default=0, help="synthetic content: 0 photo-like, 1 noise, 2 flat, 3 gradient")
     ap.add_argument("--quality", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams (one encoder context each) the steps alternate over; >1 lets the latency-bound tail "
                          "kernels of one image overlap the transform kernel of the next")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 gather path with a one-rank group (rehearsal on one GPU)")
