@@ -30,7 +30,8 @@ using namespace jpegamd;
 
 struct JpegAmdEncoder {
     int device = -1;
-    int max_w = 0, max_h = 0, max_segs = 0;
+    int max_w = 0, max_h = 0, max_segs = 0;      // max_segs: 64-block segments (sizes the per-segment arrays)
+    int max_segs_m = 0;                          // 256-block segments of the matrix-pipe kernels (sizes seg_words with kSegCapWordsM)
     // device scratch
     uint32_t *seg_words = nullptr, *seg_bits = nullptr, *seg_syms = nullptr, *seg_exact = nullptr;
     uint32_t *seg_ff = nullptr, *ovf_words = nullptr, *huff = nullptr;
@@ -136,7 +137,7 @@ static int32_t alloc_scratch(JpegAmdEncoder *e, int max_w, int max_h) {
     HIP_TRY(hipMalloc((void **)&e->seg_ff, (size_t)segs * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->seg_bitstart, ((size_t)segs + 1) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&e->seg_ffstart, ((size_t)segs + 1) * sizeof(uint64_t)));
-    e->max_w = max_w; e->max_h = max_h; e->max_segs = segs;
+    e->max_w = max_w; e->max_h = max_h; e->max_segs = segs; e->max_segs_m = segs_m;
     return JPEGAMD_OK;
 }
 
@@ -251,6 +252,17 @@ static int32_t prepare_constants(JpegAmdEncoder *e, const JpegAmdImage *img, boo
     return JPEGAMD_OK;
 }
 
+// Does a w x h image fit the scratch of `e`?  Every derived count is checked on its own: an image wider than max_w with
+// fewer rows can need MORE 256-block segments or 32-block tiles than max_w x max_h although it has fewer 64-block
+// segments (per-row rounding) -- sizing by one of the counts alone let k_entropy write past seg_words.
+static bool context_fits(const JpegAmdEncoder *e, int w, int h) {
+    if (!e || w <= 0 || h <= 0) return false;
+    const int bw = (w + 7) / 8, bh = (h + 7) / 8;
+    const int tiles = bh * ((bw + kTileBlocks - 1) / kTileBlocks);
+    return segs_for(w, h, nullptr, nullptr, nullptr) <= e->max_segs &&
+           segs_for(w, h, nullptr, nullptr, nullptr, kSegBlocksM) <= e->max_segs_m && tiles <= e->max_tiles;
+}
+
 static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageDesc *d) {
     if (!img || !img->pixels || img->width <= 0 || img->height <= 0 || img->width > 65535 || img->height > 65535)
         return JPEGAMD_ERR_ARG;
@@ -267,7 +279,7 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     d->tiles_per_row = (d->blocks_w + kTileBlocks - 1) / kTileBlocks;
     d->num_tiles = d->tiles_per_row * d->blocks_h;
     d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0) ? 1 : 0;
-    if (e && d->num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
+    if (e && !context_fits(e, img->width, img->height)) return JPEGAMD_ERR_TOO_LARGE;
     return JPEGAMD_OK;
 }
 
@@ -443,7 +455,7 @@ static JpegAmdEncoder *g_ctx = nullptr;
 static uint64_t *g_size_dev = nullptr;
 
 static int32_t ensure_ctx(int w, int h) {
-    if (g_ctx && segs_for(w, h, nullptr, nullptr, nullptr) <= g_ctx->max_segs) return JPEGAMD_OK;
+    if (g_ctx && context_fits(g_ctx, w, h)) return JPEGAMD_OK;
     int mw = w, mh = h;
     if (g_ctx) {
         if (g_ctx->max_w > mw) mw = g_ctx->max_w;

@@ -273,3 +273,19 @@ def test_file_batch_pipeline_matches_oracle(jpegamd, oracle, dev, tmp_path):
     # all files readable -> return code 0
     rc2, status2, st2 = jpegamd.encode_files(ins[:3], outs[:3])
     assert rc2 == 0 and status2 == [0, 0, 0] and st2.files_failed == 0
+
+
+@pytest.mark.gpu
+def test_context_capacity_is_checked_per_derived_count(jpegamd, oracle, dev):
+    """A context sized for 256x256 must REFUSE a 320x160 image: it has fewer 64-block segments (20 vs 32) but more
+    32-block tiles (40 vs 32).  Sizing by one count alone once let a wider-but-shorter image write past the scratch
+    (5000x3000 in a context created for 4096x4096).  The shared context of the host functions grows instead."""
+    enc = jpegamd.Encoder(256, 256)
+    ok, _ = device_encode(jpegamd, enc, jpegamd.synth_bmp(256, 256, 3, 0, 0), dev)
+    assert ok == oracle.encode_bmp(jpegamd.synth_bmp(256, 256, 3, 0, 0))
+    with pytest.raises(jpegamd.JpegAmdError) as ei:
+        device_encode(jpegamd, enc, jpegamd.synth_bmp(320, 160, 4, 0, 0), dev)
+    assert ei.value.code == -5                                        # JPEGAMD_ERR_TOO_LARGE
+    for (w, h) in [(256, 256), (320, 160), (2100, 40), (96, 900)]:    # the shared context: every shape after a different one
+        bmp = jpegamd.synth_bmp(w, h, 5, 0, 0)
+        assert jpegamd.encode_bmp_bytes(bmp) == oracle.encode_bmp(bmp), (w, h)
