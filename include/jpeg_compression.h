@@ -250,6 +250,31 @@ bool saveJPEGGrayscale(const char *filename, const BMPImage *img);
 int64_t jpegamd_encode_bmp_memory(const uint8_t *bmp, uint64_t bmp_len, int32_t quality,
                                   uint8_t *out, uint64_t out_cap);
 
+/* ---- One image sharded over several GPUs by block rows (no reference counterpart) --------
+ * Blocks are independent up to the entropy stage, which couples them only through the previous
+ * block's DC (rle.c:59-70) and the running bit offset (huffman.c:35-62).  Each rank calls
+ * jpegamd_encode_rows_async for its block rows [begin, end) of the SAME image description
+ * (it needs the pixel rows of its range and of the one block row above); the unstuffed
+ * per-segment bit strings stay in its context.  jpegamd_export_segments packs them densely:
+ * `dense_words` (used 32-bit words of the range's segments, back to back), `meta` (8 uint32 per
+ * segment: bits, word offset, tail bits, symbols, exact-path count, 0, 0, 0) and the word total.
+ * After moving both buffers to the root (RCCL), jpegamd_import_segments places them at their
+ * global segment indices in the root's context, and jpegamd_finalize_async stitches all
+ * segments: bit offsets, 0xFF stuffing and the zero-padded flush happen once, there.
+ * All four are stream-ordered; errors as jpegamd_encode_async; split pipeline only. */
+int32_t jpegamd_encode_rows_async(JpegAmdEncoder *enc, const JpegAmdImage *img, int32_t block_row_begin,
+                                  int32_t block_row_end, void *stream);
+int32_t jpegamd_export_segments(JpegAmdEncoder *enc, const JpegAmdImage *img, int32_t block_row_begin,
+                                int32_t block_row_end, uint32_t *dense_words_dev,
+                                uint64_t dense_capacity_words, uint32_t *meta_dev,
+                                uint32_t *total_words_dev, void *stream);
+int32_t jpegamd_import_segments(JpegAmdEncoder *enc, const JpegAmdImage *img, int32_t block_row_begin,
+                                int32_t block_row_end, const uint32_t *dense_words_dev,
+                                const uint32_t *meta_dev, void *stream);
+int32_t jpegamd_finalize_async(JpegAmdEncoder *enc, const JpegAmdImage *img, void *out_dev,
+                               uint64_t out_capacity, uint64_t *out_size_dev, int32_t with_container,
+                               void *stream);
+
 /* File-to-file batch encoding with the host I/O and the PCIe transfers overlapped (no
  * reference counterpart: natural_c/src/main.c:21-24 handles one file, synchronously).
  * Files are processed in order with a few in flight: pinned staging buffers, one HIP stream

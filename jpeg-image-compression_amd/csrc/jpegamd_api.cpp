@@ -278,6 +278,8 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
                            (e && e->use_mfma) ? kSegBlocksM : kSegBlocks);
     d->tiles_per_row = (d->blocks_w + kTileBlocks - 1) / kTileBlocks;
     d->num_tiles = d->tiles_per_row * d->blocks_h;
+    d->tile_begin = 0; d->tile_end = d->num_tiles;
+    d->seg_begin = 0; d->seg_end = d->num_segs;
     d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0) ? 1 : 0;
     if (e && !context_fits(e, img->width, img->height)) return JPEGAMD_ERR_TOO_LARGE;
     return JPEGAMD_OK;
@@ -323,6 +325,7 @@ static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool tap
         std::memset(&ea, 0, sizeof(ea));
         ea.tile_items = e->tile_items; ea.tile_count = e->tile_count; ea.tile_exact = e->tile_exact; ea.tile_lastdc = e->tile_lastdc;
         ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
+        ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
         ea.seg_words = e->seg_words; ea.seg_bits = e->seg_bits; ea.seg_syms = e->seg_syms; ea.seg_exact = e->seg_exact;
         ea.seg_tail = e->seg_tail;
         return launch_entropy(ea, stream);
@@ -333,6 +336,115 @@ static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool tap
     const int aan_err = launch_transform(im, e->qc, to, taps, e->std_kernel, e->entropy_backend, stream);
     if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
     return aan_err;
+}
+
+static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, uint64_t out_capacity, uint64_t *out_size_dev,
+                        int32_t with_container, hipStream_t stream) {
+    FinalizeArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.seg_words = e->seg_words; fa.seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
+    fa.seg_bits = e->seg_bits;
+    fa.seg_tail = e->use_mfma ? e->seg_tail : nullptr;
+    fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
+    fa.out = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size = out_size_dev; fa.stats = e->stats_dev;
+    fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
+    fa.write_eoi = with_container ? 1 : 0;
+    fa.seg_ff = e->seg_ff; fa.chunk_ff = e->chunk_ff; fa.chunk_b0 = e->chunk_b0;
+    return launch_finalize(fa, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One image sharded over several GPUs by block rows.  Each rank transforms and entropy-codes its rows
+// (jpegamd_encode_rows_async: the unstuffed per-segment bit strings stay in its scratch), exports them densely
+// (jpegamd_export_segments), the root imports every rank's segments at their global indices
+// (jpegamd_import_segments) and runs the ordinary finalize over all of them (jpegamd_finalize_async): bit offsets,
+// 0xFF stuffing and the zero-padded flush depend on the global byte phase and so happen once, at the root.
+// ---------------------------------------------------------------------------------------------------------
+static int32_t shard_desc(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t by0, int32_t by1, ImageDesc *im) {
+    if (!e || !e->use_mfma || !e->split_pipeline || !e->use_finalize) return JPEGAMD_ERR_ARG;   // split pipeline only
+    int32_t rc = describe(e, img, im);
+    if (rc) return rc;
+    if (by0 < 0 || by1 < by0 || by1 > im->blocks_h) return JPEGAMD_ERR_ARG;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_encode_rows_async(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t block_row_begin,
+                                             int32_t block_row_end, void *stream_) {
+    ImageDesc im;
+    int32_t rc = shard_desc(e, img, block_row_begin, block_row_end, &im);
+    if (rc) return rc;
+    rc = prepare_constants(e, img, false);
+    if (rc) return rc;
+    // the DC predictor of the shard's first block is the last block of the row above (rle.c:59-70 chains across rows):
+    // that ONE tile is transformed here too (its quantised DC does not depend on anything before it), not coded
+    im.tile_begin = block_row_begin * im.tiles_per_row - (block_row_begin > 0 ? 1 : 0);
+    im.tile_end = block_row_end * im.tiles_per_row;
+    im.seg_begin = block_row_begin * im.segs_per_row;
+    im.seg_end = block_row_end * im.segs_per_row;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (launch_any_transform(e, im, false, nullptr, nullptr, nullptr, stream, nullptr)) return JPEGAMD_ERR_HIP;
+    e->last_segs = im.num_segs;
+    e->last_stream = stream;
+    e->pending = true;
+    e->timed = false;
+    return JPEGAMD_OK;
+}
+
+static int32_t exchange_args(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t by0, int32_t by1, uint32_t *dense, uint64_t cap,
+                             uint32_t *meta, uint32_t *total, SegExchange *x) {
+    ImageDesc im;
+    int32_t rc = shard_desc(e, img, by0, by1, &im);
+    if (rc) return rc;
+    if (!dense || !meta) return JPEGAMD_ERR_ARG;
+    std::memset(x, 0, sizeof(*x));
+    x->seg_words = e->seg_words; x->seg_stride = (uint32_t)kSegCapWordsM;
+    x->seg_bits = e->seg_bits; x->seg_syms = e->seg_syms; x->seg_exact = e->seg_exact; x->seg_tail = e->seg_tail;
+    x->s0 = by0 * im.segs_per_row; x->s1 = by1 * im.segs_per_row;
+    x->dense = dense; x->dense_cap_words = cap; x->meta = meta; x->total_words = total;
+    x->status = &e->stats_dev->status;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_export_segments(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t block_row_begin, int32_t block_row_end,
+                                           uint32_t *dense_words_dev, uint64_t dense_capacity_words, uint32_t *meta_dev,
+                                           uint32_t *total_words_dev, void *stream) {
+    SegExchange x;
+    if (!total_words_dev) return JPEGAMD_ERR_ARG;
+    int32_t rc = exchange_args(e, img, block_row_begin, block_row_end, dense_words_dev, dense_capacity_words, meta_dev, total_words_dev, &x);
+    if (rc) return rc;
+    if (launch_seg_export(x, stream)) return JPEGAMD_ERR_HIP;
+    e->last_stream = (hipStream_t)stream; e->pending = true; e->timed = false;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_import_segments(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t block_row_begin, int32_t block_row_end,
+                                           const uint32_t *dense_words_dev, const uint32_t *meta_dev, void *stream) {
+    SegExchange x;
+    int32_t rc = exchange_args(e, img, block_row_begin, block_row_end, const_cast<uint32_t *>(dense_words_dev), ~0ull,
+                               const_cast<uint32_t *>(meta_dev), nullptr, &x);
+    if (rc) return rc;
+    if (launch_seg_import(x, stream)) return JPEGAMD_ERR_HIP;
+    e->last_stream = (hipStream_t)stream; e->pending = true; e->timed = false;
+    return JPEGAMD_OK;
+}
+
+extern "C" int32_t jpegamd_finalize_async(JpegAmdEncoder *e, const JpegAmdImage *img, void *out_dev, uint64_t out_capacity,
+                                          uint64_t *out_size_dev, int32_t with_container, void *stream_) {
+    if (!out_dev || !out_size_dev) return JPEGAMD_ERR_ARG;
+    ImageDesc im;
+    int32_t rc = shard_desc(e, img, 0, 0, &im);
+    if (rc) return rc;
+    rc = prepare_constants(e, img, with_container != 0);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    // the status word is normally cleared by the transform kernel of the same call
+    HIP_TRY(hipMemsetAsync(&e->stats_dev->status, 0, sizeof(uint32_t), stream));
+    if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
+    e->last_segs = im.num_segs;
+    e->last_stream = stream;
+    e->pending = true;
+    e->timed = false;
+    return JPEGAMD_OK;
 }
 
 extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *img, void *out_dev,
@@ -358,16 +470,7 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
     const uint32_t seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
     if (e->use_finalize) {
         if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
-        FinalizeArgs fa;
-        std::memset(&fa, 0, sizeof(fa));
-        fa.seg_words = e->seg_words; fa.seg_stride = seg_stride; fa.seg_bits = e->seg_bits;
-        fa.seg_tail = e->use_mfma ? e->seg_tail : nullptr;
-        fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
-        fa.out = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size = out_size_dev; fa.stats = e->stats_dev;
-        fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
-        fa.write_eoi = with_container ? 1 : 0;
-        fa.seg_ff = e->seg_ff; fa.chunk_ff = e->chunk_ff; fa.chunk_b0 = e->chunk_b0;
-        if (launch_finalize(fa, stream)) return JPEGAMD_ERR_HIP;
+        if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
     } else {
         if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
         if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
@@ -511,7 +614,7 @@ int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64
     rc = describe(e, img, &im);
     if (rc) return rc;
     im.blocks_w = 1; im.blocks_h = 1; im.segs_per_row = 1; im.num_segs = 1;   // block (0,0) only
-    im.tiles_per_row = 1; im.num_tiles = 1;
+    im.tiles_per_row = 1; im.num_tiles = 1; im.tile_begin = 0; im.tile_end = 1; im.seg_begin = 0; im.seg_end = 1;
     int8_t *y_dev = nullptr; int16_t *zz_dev = nullptr; float *dct_dev = nullptr;
     HIP_TRY(hipMalloc((void **)&y_dev, 64));
     HIP_TRY(hipMalloc((void **)&zz_dev, 128));

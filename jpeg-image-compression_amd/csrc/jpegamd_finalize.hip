@@ -431,6 +431,73 @@ int launch_finalize(const FinalizeArgs &a, void *stream) {
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Segment exchange (one image sharded over GPUs by block rows): used words of segments [s0, s1) packed densely +
+// 8 metadata words per segment {bits, word offset, tail, symbols, exact-path count, 0, 0, 0}; and the inverse.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_seg_offsets(const SegExchange x) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int n = x.s1 - x.s0, lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) s_carry = 0u;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const uint32_t bits = i < n ? x.seg_bits[x.s0 + i] : 0u;
+        const uint32_t nw = (bits + 31u) >> 5;
+        const uint32_t incl = wave_incl_scan_u32(nw);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_w[w];
+        if (i < n) {
+            uint32_t *m = x.meta + (size_t)i * 8;
+            m[0] = bits; m[1] = before + incl - nw; m[2] = x.seg_tail[x.s0 + i];
+            m[3] = x.seg_syms[x.s0 + i]; m[4] = x.seg_exact[x.s0 + i]; m[5] = m[6] = m[7] = 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *x.total_words = s_carry;
+        if ((uint64_t)s_carry > x.dense_cap_words) atomicOr(x.status, 1u);
+    }
+}
+
+template <bool kExport>
+__global__ __launch_bounds__(256) void k_seg_copy(const SegExchange x) {
+    const int lane = lane_id();
+    const int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= x.s1 - x.s0) return;
+    const uint32_t *m = x.meta + (size_t)i * 8;
+    const uint32_t bits = m[0], off = m[1], nw = (bits + 31u) >> 5;
+    uint32_t *strided = x.seg_words + (size_t)(x.s0 + i) * x.seg_stride;
+    if (kExport) {
+        if ((uint64_t)off + nw > x.dense_cap_words) return;           // flagged by k_seg_offsets
+        for (uint32_t j = (uint32_t)lane; j < nw; j += 64) x.dense[off + j] = strided[j];
+    } else {
+        for (uint32_t j = (uint32_t)lane; j < nw; j += 64) strided[j] = x.dense[off + j];
+        if (lane == 0) {
+            x.seg_bits[x.s0 + i] = bits; x.seg_tail[x.s0 + i] = (uint8_t)m[2];
+            x.seg_syms[x.s0 + i] = m[3]; x.seg_exact[x.s0 + i] = m[4];
+        }
+    }
+}
+
+int launch_seg_export(const SegExchange &x, void *stream) {
+    const int n = x.s1 - x.s0;
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1024), 0, (hipStream_t)stream, x);
+    if (n > 0) hipLaunchKernelGGL(k_seg_copy<true>, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x);
+    return (int)hipGetLastError();
+}
+
+int launch_seg_import(const SegExchange &x, void *stream) {
+    const int n = x.s1 - x.s0;
+    if (n > 0) hipLaunchKernelGGL(k_seg_copy<false>, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x);
+    return (int)hipGetLastError();
+}
+
 // Sums of the per-segment symbol / exact-path counters, on request (jpegamd_encoder_finish with stats).
 __global__ __launch_bounds__(1024) void k_sum_stats(const uint32_t *__restrict__ seg_syms, const uint32_t *__restrict__ seg_exact,
                                                      int n, ScanStats *stats) {

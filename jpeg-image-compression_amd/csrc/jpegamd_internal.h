@@ -95,6 +95,19 @@ struct FinalizeArgs {
     unsigned long long *chunk_b0;   // [num_chunks] bit offset of the chunk
 };
 int launch_finalize(const FinalizeArgs &a, void *stream);
+// Segment exchange for one image sharded over GPUs by block rows (jpegamd_finalize.hip): dense copy of the used words of
+// segments [s0, s1) + 8 words of metadata per segment (bits, word offset, tail, symbols, exact-path count), and back.
+struct SegExchange {
+    uint32_t *seg_words; uint32_t seg_stride;
+    uint32_t *seg_bits, *seg_syms, *seg_exact; uint8_t *seg_tail;
+    int32_t s0, s1;
+    uint32_t *dense; uint64_t dense_cap_words;
+    uint32_t *meta;                 // [s1 - s0][8]
+    uint32_t *total_words;          // [1] (export: written; import: unused)
+    uint32_t *status;               // ScanStats::status word: bit 0 set when dense_cap_words was too small
+};
+int launch_seg_export(const SegExchange &x, void *stream);
+int launch_seg_import(const SegExchange &x, void *stream);
 int launch_sum_stats(const uint32_t *seg_syms, const uint32_t *seg_exact, int n, ScanStats *stats, void *stream);
 int finalize_chunks(int num_segs);
 
@@ -104,6 +117,8 @@ struct ImageDesc {
     uint32_t weights;          // luma weights for stored bytes 0,1,2 (byte 3 = 0)
     int32_t blocks_w, blocks_h, segs_per_row, num_segs;
     int32_t tiles_per_row, num_tiles;   // 32-block tiles (matrix-pipe kernels)
+    int32_t tile_begin, tile_end;       // tiles this launch transforms (whole image: 0, num_tiles; a block-row shard otherwise)
+    int32_t seg_begin, seg_end;         // segments this launch codes
     int32_t fast_ok;           // pixels % 4 == 0 && row_stride % 4 == 0
 };
 
@@ -174,6 +189,7 @@ struct EntropyArgs {            // k_entropy: per-tile symbol lists -> per-segme
     const int32_t *tile_lastdc;
     const uint32_t *huff;
     int32_t num_segs, segs_per_row, tiles_per_row;
+    int32_t seg_begin, seg_end;     // segments this launch codes (whole image: 0, num_segs)
     uint32_t *seg_words, *seg_bits, *seg_syms, *seg_exact;
     uint8_t *seg_tail;
 };

@@ -147,8 +147,8 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     const int groups = 1 << sch.grp_shift;
     const int grp = (int)blockIdx.x & (groups - 1);
     const int grp_waves = ((((int)gridDim.x - 1 - grp) >> sch.grp_shift) + 1) * kWavesT;   // waves of this group
-    const int grp_lo = min(grp * sch.tiles_per_group, im.num_tiles);
-    const int grp_hi = min(grp_lo + sch.tiles_per_group, im.num_tiles);
+    const int grp_lo = min(im.tile_begin + grp * sch.tiles_per_group, im.tile_end);
+    const int grp_hi = min(grp_lo + sch.tiles_per_group, im.tile_end);
     uint32_t *ctr = out.tile_ctr + grp * 32;                                                // [0] tickets, [1] waves done
     const int first = grp_lo + ((int)blockIdx.x >> sch.grp_shift) * kWavesT + wave;
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
@@ -448,13 +448,15 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 
 int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream) {
     // persistent: at most 2 workgroups per CU (16 waves/CU at 4 waves/SIMD), fewer for small images
-    const int wgs_all = (im.num_tiles + kWavesT - 1) / kWavesT;
+    const int ntiles = im.tile_end - im.tile_begin;
+    if (ntiles <= 0) return 0;
+    const int wgs_all = (ntiles + kWavesT - 1) / kWavesT;
     const int wgs = wgs_all < 512 ? wgs_all : 512;
     TileSched sch;
     sch.grp_shift = 0;
     while ((2 << sch.grp_shift) <= wgs && (2 << sch.grp_shift) <= kTileGroups) ++sch.grp_shift;
     const int groups = 1 << sch.grp_shift;
-    sch.tiles_per_group = (im.num_tiles + groups - 1) / groups;
+    sch.tiles_per_group = (ntiles + groups - 1) / groups;
     const uint64_t magic = 0x100000000ull / (uint64_t)im.tiles_per_row + 1ull;
     sch.tpr_magic = magic > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)magic;   // tiles_per_row == 1: the correction step makes up for it
     const dim3 grid(wgs), block(64 * kWavesT);
@@ -479,8 +481,8 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     }
     __syncthreads();
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int seg = (int)blockIdx.x * kWavesE + wave;
-    if (seg >= a.num_segs) return;
+    const int seg = a.seg_begin + (int)blockIdx.x * kWavesE + wave;
+    if (seg >= a.seg_end) return;
     uint32_t *win = s_win[wave];
 
     const int by = seg / a.segs_per_row;
@@ -595,7 +597,8 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
 }
 
 int launch_entropy(const EntropyArgs &a, void *stream) {
-    hipLaunchKernelGGL(k_entropy, dim3((a.num_segs + kWavesE - 1) / kWavesE), dim3(64 * kWavesE), 0, (hipStream_t)stream, a);
+    if (a.seg_end <= a.seg_begin) return 0;
+    hipLaunchKernelGGL(k_entropy, dim3((a.seg_end - a.seg_begin + kWavesE - 1) / kWavesE), dim3(64 * kWavesE), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

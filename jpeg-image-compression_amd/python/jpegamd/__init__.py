@@ -85,6 +85,10 @@ def _load() -> C.CDLL:
         "saveJPEGGrayscale": (C.c_bool, [C.c_char_p, C.POINTER(BMPImage)]),
         "jpegamd_encode_bmp_memory": (i64, [vp, u64, i32, vp, u64]),
         "jpegamd_parse_bmp": (i32, [vp, u64, C.POINTER(Image), C.POINTER(u64)]),
+        "jpegamd_encode_rows_async": (i32, [vp, C.POINTER(Image), i32, i32, vp]),
+        "jpegamd_export_segments": (i32, [vp, C.POINTER(Image), i32, i32, vp, u64, vp, vp, vp]),
+        "jpegamd_import_segments": (i32, [vp, C.POINTER(Image), i32, i32, vp, vp, vp]),
+        "jpegamd_finalize_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -97,7 +101,8 @@ EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_byt
             "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
             "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts jpegamd_debug_mfma_consts JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
-            "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files").split()
+            "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files "
+            "jpegamd_encode_rows_async jpegamd_export_segments jpegamd_import_segments jpegamd_finalize_async").split()
 
 
 def quant_consts(quality: int = 50):
@@ -232,6 +237,31 @@ class Encoder:
                                       1 if with_container else 0, C.c_void_p(stream))
         if rc:
             raise JpegAmdError(rc, "jpegamd_encode_async")
+
+    # ---- one image sharded over GPUs by block rows (include/jpeg_compression.h) ----
+    def encode_rows_async(self, img: Image, row_begin: int, row_end: int, stream: int = 0):
+        rc = lib.jpegamd_encode_rows_async(self._h, C.byref(img), C.c_int32(row_begin), C.c_int32(row_end), C.c_void_p(stream))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encode_rows_async")
+
+    def export_segments(self, img: Image, row_begin: int, row_end: int, dense_ptr: int, dense_cap_words: int, meta_ptr: int,
+                        total_ptr: int, stream: int = 0):
+        rc = lib.jpegamd_export_segments(self._h, C.byref(img), C.c_int32(row_begin), C.c_int32(row_end), C.c_void_p(dense_ptr),
+                                         C.c_uint64(dense_cap_words), C.c_void_p(meta_ptr), C.c_void_p(total_ptr), C.c_void_p(stream))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_export_segments")
+
+    def import_segments(self, img: Image, row_begin: int, row_end: int, dense_ptr: int, meta_ptr: int, stream: int = 0):
+        rc = lib.jpegamd_import_segments(self._h, C.byref(img), C.c_int32(row_begin), C.c_int32(row_end), C.c_void_p(dense_ptr),
+                                         C.c_void_p(meta_ptr), C.c_void_p(stream))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_import_segments")
+
+    def finalize_async(self, img: Image, out_ptr: int, out_cap: int, size_ptr: int, with_container: bool = True, stream: int = 0):
+        rc = lib.jpegamd_finalize_async(self._h, C.byref(img), C.c_void_p(out_ptr), C.c_uint64(out_cap), C.c_void_p(size_ptr),
+                                        1 if with_container else 0, C.c_void_p(stream))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_finalize_async")
 
     def finish(self) -> Stats:
         st = Stats()

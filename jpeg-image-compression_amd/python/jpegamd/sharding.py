@@ -158,3 +158,92 @@ class BatchedStreamGather:
                 streams.append(bytes(rec[:n].numpy()))
             out.append(streams)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One image over several GPUs: contiguous block-row shards, one exchange step.
+# ---------------------------------------------------------------------------------------------------------------
+class ShardedImageEncoder:
+    """Encode ONE image with `world` ranks: rank r transforms and entropy-codes block rows shard_range(blocks_h, world, r)
+    into unstuffed per-segment bit strings, packs them densely, the root collects every rank's pack (one size
+    all-reduce + one padded gather per image) and runs the ordinary finalize over all segments -- bit offsets, 0xFF
+    stuffing and the flush depend on the global byte phase, so they happen once, at the root.
+
+    `encoder` is a jpegamd.Encoder sized for the image; buffers are allocated once for `max_words` packed words per
+    rank (a rank's share of the worst case by default).  With `group=None` and torch.distributed not initialised the
+    object runs as a single rank (useful for tests: `virtual_ranks` splits the work over several contexts on ONE GPU).
+    """
+
+    def __init__(self, encoder, width: int, height: int, device, group=None, dst: int = 0, max_words: Optional[int] = None):
+        self.enc, self.w, self.h, self.device, self.group, self.dst = encoder, width, height, device, group, dst
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist_on else 1
+        self.rank = dist.get_rank(group) if self.dist_on else 0
+        self.blocks_w, self.blocks_h = (width + 7) // 8, (height + 7) // 8
+        self.segs_per_row = (self.blocks_w + 255) // 256
+        rows = -(-self.blocks_h // self.world)
+        nseg = rows * self.segs_per_row
+        if max_words is None:
+            max_words = nseg * ((256 * 1721 + 31) // 32 + 1)          # every block at the worst-case bit count
+        self.max_words, self.max_segs = int(max_words), nseg
+        self.dense = torch.empty(self.max_words, dtype=torch.int32, device=device)
+        self.meta = torch.zeros(nseg * 8, dtype=torch.int32, device=device)
+        self.total = torch.zeros(1, dtype=torch.int32, device=device)
+        if self.rank == dst and self.world > 1:
+            self.recv_dense = [torch.empty(self.max_words, dtype=torch.int32, device=device) for _ in range(self.world)]
+            self.recv_meta = [torch.empty(nseg * 8, dtype=torch.int32, device=device) for _ in range(self.world)]
+
+    def rows_of(self, rank: int) -> Tuple[int, int]:
+        return shard_range(self.blocks_h, self.world, rank)
+
+    def encode(self, img, out: torch.Tensor, out_size: torch.Tensor, with_container: bool = True, stream: int = 0) -> None:
+        """Collective: every rank calls it with the same image description (its `pixels` must cover the rank's rows and
+        the block row above).  On `dst` the JFIF bytes land in `out`, their count in `out_size` (device int64)."""
+        by0, by1 = self.rows_of(self.rank)
+        self.enc.encode_rows_async(img, by0, by1, stream)
+        self.enc.export_segments(img, by0, by1, self.dense.data_ptr(), self.max_words, self.meta.data_ptr(), self.total.data_ptr(), stream)
+        if self.world == 1:
+            self.enc.finalize_async(img, out.data_ptr(), out.numel(), out_size.data_ptr(), with_container, stream)
+            return
+        # one padded gather per buffer: the pad is the allocation, the payload size travels inside `meta`
+        g1 = dist.gather(self.dense, self.recv_dense if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+        g2 = dist.gather(self.meta, self.recv_meta if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
+        g1.wait()
+        g2.wait()
+        if self.rank == self.dst:
+            for r in range(self.world):
+                if r == self.rank:
+                    continue                                              # the root's own segments are already in place
+                b0, b1 = self.rows_of(r)
+                self.enc.import_segments(img, b0, b1, self.recv_dense[r].data_ptr(), self.recv_meta[r].data_ptr(), stream)
+            self.enc.finalize_async(img, out.data_ptr(), out.numel(), out_size.data_ptr(), with_container, stream)
+
+
+def encode_image_virtual_ranks(jpegamd, img, width: int, height: int, ranks: int, device, root_encoder=None):
+    """Single-GPU rehearsal of the sharded path: `ranks` separate encoder contexts each code their block rows, every
+    pack is imported into a root context, which finalizes.  Returns the JFIF bytes."""
+    blocks_h = (height + 7) // 8
+    spr = ((width + 7) // 8 + 255) // 256
+    root = root_encoder or jpegamd.Encoder(width, height)
+    packs = []
+    for r in range(ranks):
+        b0, b1 = shard_range(blocks_h, ranks, r)
+        enc = jpegamd.Encoder(width, height)
+        nseg = max(1, (b1 - b0) * spr)
+        words = nseg * ((256 * 1721 + 31) // 32 + 1)
+        dense = torch.empty(words, dtype=torch.int32, device=device)
+        meta = torch.zeros(nseg * 8, dtype=torch.int32, device=device)
+        total = torch.zeros(1, dtype=torch.int32, device=device)
+        enc.encode_rows_async(img, b0, b1, 0)
+        enc.export_segments(img, b0, b1, dense.data_ptr(), words, meta.data_ptr(), total.data_ptr(), 0)
+        enc.finish()
+        n = int(total.item())
+        packs.append((b0, b1, dense[:max(n, 1)].clone(), meta))
+    for b0, b1, dense, meta in packs:
+        root.import_segments(img, b0, b1, dense.data_ptr(), meta.data_ptr(), 0)
+    cap = 4096 + 2 * width * height
+    out = torch.empty(cap, dtype=torch.uint8, device=device)
+    size = torch.zeros(1, dtype=torch.int64, device=device)
+    root.finalize_async(img, out.data_ptr(), cap, size.data_ptr(), True, 0)
+    root.finish()
+    return bytes(out[:int(size.item())].cpu().numpy())

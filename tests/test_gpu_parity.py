@@ -289,3 +289,36 @@ def test_context_capacity_is_checked_per_derived_count(jpegamd, oracle, dev):
     for (w, h) in [(256, 256), (320, 160), (2100, 40), (96, 900)]:    # the shared context: every shape after a different one
         bmp = jpegamd.synth_bmp(w, h, 5, 0, 0)
         assert jpegamd.encode_bmp_bytes(bmp) == oracle.encode_bmp(bmp), (w, h)
+
+
+@pytest.mark.gpu
+def test_one_image_sharded_by_block_rows(jpegamd, oracle, dev):
+    """SURVEY.md 8e, single large image: every 'rank' (a separate context here) codes its block rows into unstuffed
+    segments, the root imports all packs and finalizes once.  Bytes equal the oracle's for even and ragged splits,
+    one- and several-segment rows, narrow images (one tile per row), and more ranks than block rows."""
+    from jpegamd.sharding import encode_image_virtual_ranks
+    for (w, h, kind, ranks) in [(640, 480, 0, 2), (2100, 333, 1, 3), (200, 120, 0, 4), (4200, 160, 0, 8), (64, 40, 1, 7), (1024, 1024, 0, 5)]:
+        bmp = jpegamd.synth_bmp(w, h, 40 + ranks, kind, 0)
+        img, px = upload_pixels(bmp, jpegamd, dev)
+        d = jpegamd.Encoder.image(px.data_ptr(), img.width, img.height, img.row_stride, bool(img.bottom_up), jpegamd.ORDER_BGR, 0)
+        got = encode_image_virtual_ranks(jpegamd, d, w, h, ranks, dev)
+        assert got == oracle.encode_bmp(bmp), (w, h, kind, ranks)
+
+
+@pytest.mark.gpu
+def test_sharded_image_encoder_single_rank(jpegamd, oracle, dev):
+    """jpegamd.sharding.ShardedImageEncoder without a process group: rows -> export -> finalize on one context."""
+    from jpegamd.sharding import ShardedImageEncoder
+    w, h = 777, 333
+    bmp = jpegamd.synth_bmp(w, h, 12, 0, 0)
+    img, px = upload_pixels(bmp, jpegamd, dev)
+    d = jpegamd.Encoder.image(px.data_ptr(), img.width, img.height, img.row_stride, bool(img.bottom_up), jpegamd.ORDER_BGR, 0)
+    enc = jpegamd.Encoder(w, h)
+    she = ShardedImageEncoder(enc, w, h, dev)
+    cap = 4096 + 2 * w * h
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    size = torch.zeros(1, dtype=torch.int64, device=dev)
+    she.encode(d, out, size)
+    enc.finish()
+    assert bytes(out[:int(size.item())].cpu().numpy()) == oracle.encode_bmp(bmp)
+    assert int(she.total.item()) > 0 and she.rows_of(0) == (0, (h + 7) // 8)

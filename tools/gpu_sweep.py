@@ -22,8 +22,10 @@ for i in range(n):
         w, h = rng.randint(1, 300), rng.randint(1, 200)
     elif cls < 0.8:
         w, h = rng.randint(250, 2100), rng.randint(8, 64)            # wide: many tiles per row, partial last tiles
-    else:
+    elif cls < 0.97:
         w, h = rng.randint(300, 1400), rng.randint(200, 900)
+    else:
+        w, h = rng.randint(1500, 6000), rng.randint(100, 2500)         # occasional large shapes: the shared context grows in steps
     seed, kind, flags = rng.randint(1, 10 ** 6), rng.randint(0, 3), rng.randint(0, 3)
     q = rng.choice([50, 50, 50, 10, 90])
     bmp = jpegamd.synth_bmp(w, h, seed, kind, flags)
