@@ -322,3 +322,31 @@ def test_sharded_image_encoder_single_rank(jpegamd, oracle, dev):
     enc.finish()
     assert bytes(out[:int(size.item())].cpu().numpy()) == oracle.encode_bmp(bmp)
     assert int(she.total.item()) > 0 and she.rows_of(0) == (0, (h + 7) // 8)
+
+
+@pytest.mark.gpu
+def test_stage_functions_match_the_oracle_stage_by_stage(jpegamd, oracle, dev):
+    """The reference's own verification method: every stage function (natural_c_stages.h, GPU kernels behind them)
+    against the same stage of the oracle -- luma, centring, float32 DCT bit for bit, quantiser, zigzag, RLE symbols,
+    entropy-coded bytes -- and the chained result against the whole-pipeline encoder."""
+    from jpegamd import stages
+    for (w, h, seed, kind) in [(96, 64, 1, 0), (203, 117, 5, 1), (64, 64, 101, 2), (333, 250, 4, 0), (8, 8, 2, 1)]:
+        bmp = jpegamd.synth_bmp(w, h, seed, kind, 1)                   # top-down: rows already in BMPImage order
+        img, off = jpegamd.parse_bmp(bmp)
+        assert not img.bottom_up and img.channel_order == jpegamd.ORDER_BGR
+        rows = np.frombuffer(bmp, np.uint8, offset=off).reshape(h, img.row_stride)[:, :3 * w].reshape(h, w, 3)
+        rgb = rows[:, :, ::-1]                                          # loadBMPImage swaps BGR -> RGB (bmp_handler.c:112-120)
+        got = stages.run_stages(rgb)
+        exp = oracle.stages(bmp)
+        assert np.array_equal(got["centered"], exp["y"]) and np.array_equal(got["y"].astype(np.int16) - 128, exp["y"].astype(np.int16))
+        assert np.array_equal(got["dct"].view(np.uint32), exp["dct"].view(np.uint32)), (w, h, "dct bits")
+        assert np.array_equal(got["quant"], exp["quant"]) and np.array_equal(got["zigzag"], exp["zigzag"])
+        assert got["blocks"] == ((w + 7) // 8, (h + 7) // 8, ((w + 7) // 8) * ((h + 7) // 8))
+        assert got["rle"] == oracle.rle_symbols(exp["zigzag"])
+        assert got["entropy"] == oracle.entropy(exp["zigzag"])
+        whole = jpegamd.encode_bmp_bytes(bmp)
+        assert whole == oracle.jfif_prefix(w, h) + got["entropy"] + b"\xff\xd9"
+    blk = (np.arange(64).reshape(8, 8) * 3 - 90).astype(np.int8)
+    out = np.zeros((8, 8), np.float32)
+    jpegamd.lib.computeDCTBlock(blk.ctypes.data, out.ctypes.data)
+    assert np.array_equal(out.view(np.uint32), oracle.dct_blocks(blk[None])[0].view(np.uint32))

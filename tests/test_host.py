@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol(jpegamd):
     assert set(jpegamd.EXPORTED) == declared
 
 
+def test_library_exports_the_stage_interface(jpegamd):
+    """include/natural_c_stages.h: every declared stage function / free function is exported, struct sizes match the reference's."""
+    header = (ROOT / "include" / "natural_c_stages.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", header))
+    from jpegamd import stages
+    assert declared == set(stages.STAGE_EXPORTS)
+    raw = ctypes.CDLL(str(jpegamd.LIB_PATH))
+    assert not [s for s in sorted(declared) if not hasattr(raw, s)]
+    assert ctypes.sizeof(stages.RLESymbol) == 6 and ctypes.sizeof(stages.RLEData) == 24 and ctypes.sizeof(stages.ZigZagData) == 24
+    assert ctypes.sizeof(stages.YImage) == 16 and ctypes.sizeof(stages.JpegEncoderBuffer) == 24
+
+
 def test_struct_layouts_match_header(jpegamd):
     # natural_c/include/bmp_handler.h:37-41 and the DTO field order of jpeg_compression.h:32-64
     assert ctypes.sizeof(jpegamd.BMPImage) == 16
