@@ -234,6 +234,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         step(W + i)
+    t_issued = time.perf_counter()                               # host-side cost of enqueueing the K steps
     drain()
     if dist is not None:
         dist.barrier()
@@ -340,6 +341,7 @@ def main():
                      "measured": roof_note,
                      "overlapped_us": {"transform": round(ov_tr / 1e3, 2), "entropy": round(ov_en / 1e3, 2),
                                        "pack": round(ov_pk / 1e3, 2), "total": round(ov_tot / 1e3, 2)}},
+        "host_issue_us_per_step": round((t_issued - t0) / K * 1e6, 2),
         "jfif_bytes": len(out_bytes),
         "exact_fallbacks_per_image": int(st.exact_fallbacks),
         "parity": parity,

@@ -28,7 +28,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define JPEGAMD_AFR_BATCH 2
 #endif
 constexpr int kAfrBatch = JPEGAMD_AFR_BATCH;   // k-steps whose A fragments (2 x 4 VGPRs each) are in registers at once
-constexpr int kWavesT = 8;                      // 512-thread workgroups share the 24 KiB matrix image in LDS
+#ifndef JPEGAMD_TILE_WG_WAVES
+#define JPEGAMD_TILE_WG_WAVES 8
+#endif
+#ifndef JPEGAMD_TILE_MAX_WGS
+#define JPEGAMD_TILE_MAX_WGS 512
+#endif
+constexpr int kWavesT = JPEGAMD_TILE_WG_WAVES;  // waves per workgroup; they share the 24 KiB matrix image in LDS
 constexpr uint32_t kItDc = 0x80000000u;         // item is a DC difference
 constexpr uint32_t kItFirst = 0x40000000u;      // ... of the first block of its tile: value is the absolute DC
 
@@ -451,7 +457,7 @@ int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool ta
     const int ntiles = im.tile_end - im.tile_begin;
     if (ntiles <= 0) return 0;
     const int wgs_all = (ntiles + kWavesT - 1) / kWavesT;
-    const int wgs = wgs_all < 512 ? wgs_all : 512;
+    const int wgs = wgs_all < JPEGAMD_TILE_MAX_WGS ? wgs_all : JPEGAMD_TILE_MAX_WGS;
     TileSched sch;
     sch.grp_shift = 0;
     while ((2 << sch.grp_shift) <= wgs && (2 << sch.grp_shift) <= kTileGroups) ++sch.grp_shift;

@@ -27,7 +27,7 @@ for i in range(n):
     else:
         w, h = rng.randint(1500, 6000), rng.randint(100, 2500)         # occasional large shapes: the shared context grows in steps
     seed, kind, flags = rng.randint(1, 10 ** 6), rng.randint(0, 3), rng.randint(0, 3)
-    q = rng.choice([50, 50, 50, 10, 90])
+    q = rng.choice([50, 50, 50, 10, 90, rng.randint(1, 100)])
     bmp = jpegamd.synth_bmp(w, h, seed, kind, flags)
     got = jpegamd.encode_bmp_bytes(bmp, q if q != 50 else 0)
     exp = oracle.encode_bmp(bmp, q)
