@@ -52,15 +52,20 @@ __device__ __forceinline__ bf16x8 luma_row8_bf16(const RawRow &raw, uint32_t w) 
     const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu;
     const uint32_t wA = w, wB0 = c0 << 24, wB1 = c1 | (c2 << 8), wC0 = (c0 << 16) | (c1 << 24), wC1 = c2, wD = w << 8;
     const uint32_t kC = 0xFFFF8000u;
+    // the centred luma is the signed byte at bits 8..15 of (sum - 32768): written as a byte extraction so that the
+    // conversion can take it straight from the dot product's register (SDWA byte select) without a separate shift
+    uint32_t sdot[8];
+    sdot[0] = __builtin_amdgcn_udot4(d0, wA, kC, false);
+    sdot[1] = __builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, kC, false), false);
+    sdot[2] = __builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, kC, false), false);
+    sdot[3] = __builtin_amdgcn_udot4(d2, wD, kC, false);
+    sdot[4] = __builtin_amdgcn_udot4(d3, wA, kC, false);
+    sdot[5] = __builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, kC, false), false);
+    sdot[6] = __builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, kC, false), false);
+    sdot[7] = __builtin_amdgcn_udot4(d5, wD, kC, false);
     int y[8];
-    y[0] = (int)__builtin_amdgcn_udot4(d0, wA, kC, false) >> 8;
-    y[1] = (int)__builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, kC, false), false) >> 8;
-    y[2] = (int)__builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, kC, false), false) >> 8;
-    y[3] = (int)__builtin_amdgcn_udot4(d2, wD, kC, false) >> 8;
-    y[4] = (int)__builtin_amdgcn_udot4(d3, wA, kC, false) >> 8;
-    y[5] = (int)__builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, kC, false), false) >> 8;
-    y[6] = (int)__builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, kC, false), false) >> 8;
-    y[7] = (int)__builtin_amdgcn_udot4(d5, wD, kC, false) >> 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = (int)(int8_t)(sdot[j] >> 8);
     bf16x8 r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = (__bf16)(float)y[j];      // |y| <= 128: exact in bf16
