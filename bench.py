@@ -8,14 +8,17 @@ Rank 0 prints ONE JSON line.
 Workload (BASELINE.json configs[2], the config the roofline target is quoted on): one
 8192x8192 synthetic 24-bit BMP per rank per step, reference quantisation table (Q=50),
 pixel rows already resident in HBM; output = complete JFIF file bytes in HBM.  A "step" is
-one pass of the hot path (fused transform kernel -> bit-offset scan -> 0xFF count -> scan ->
-stitch/stuff) over one image.  Inputs rotate over 3 distinct images per rank (603 MB > the
-256 MiB Infinity Cache).  With N > 1 every rank encodes its own images (weak scaling, no
-data-path collective inside the encode) and the finished bitstreams are gathered at rank 0
-with an asynchronous padded gather (RCCL), overlapped with the next step.
+one pass of the hot path (k_tile_transform -> k_entropy -> k_fin_count2 -> k_fin_write2) over one
+image.  Inputs rotate over 3 distinct images per rank (603 MB > the 256 MiB Infinity Cache).  Steps
+alternate over `--streams` encoder contexts / HIP streams (default 4) so the tail kernels of one
+image overlap the transform of the next; every step is still one complete encode.  With N > 1 every
+rank encodes its own images (weak scaling, no data-path collective inside the encode) and the
+finished bitstreams are collected at rank 0 with one asynchronous RCCL gather per `--gather-every`
+images (jpegamd.sharding.BatchedStreamGather), overlapped with the following steps.
 
-Extra objects on the JSON line: "roofline" (dominant kernel = k_transform, HIP-event timed
-inside this run through the C-ABI's event ring) and "cpu_baseline" (the compiled reference
+Extra objects on the JSON line: "roofline" (dominant kernel = k_tile_transform, HIP-event timed
+inside this run through the C-ABI's event ring; with several streams the durations come from a
+single-stream pass right after the timed region) and "cpu_baseline" (the compiled reference
 natural_c, single thread, on a bounded sample; rank 0, N == 1 only).
 """
 from __future__ import annotations
