@@ -366,3 +366,32 @@ def test_retained_kernel_variants_stay_bit_exact(jpegamd, oracle, dev, variant, 
         bmp = jpegamd.synth_bmp(w, h, seed, kind, flags)
         got, _ = device_encode(jpegamd, enc, bmp, dev)
         assert got == oracle.encode_bmp(bmp), (variant, w, h, kind)
+
+
+@pytest.mark.gpu
+def test_concurrent_streams_and_contexts(jpegamd, oracle, dev):
+    """bench.py's default mode: several encoder contexts on several HIP streams with many encodes in flight and no host
+    synchronisation in between.  Every output (not only the last) must equal the oracle's."""
+    shapes = [(640, 480, 0), (1000, 700, 1), (333, 250, 0), (1280, 64, 3), (96, 1100, 0), (1024, 1024, 2)]
+    bmps = [jpegamd.synth_bmp(w, h, 900 + i, kind, i & 1) for i, (w, h, kind) in enumerate(shapes)]
+    ups = [upload_pixels(b, jpegamd, dev) for b in bmps]
+    nstreams, rounds = 3, 4
+    encs = [jpegamd.Encoder(1280, 1100) for _ in range(nstreams)]
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    jobs = []
+    for r in range(rounds):
+        for i, (img, px) in enumerate(ups):
+            k = len(jobs) % nstreams
+            cap = 4096 + 2 * img.width * img.height
+            out = torch.empty(cap, dtype=torch.uint8, device=dev)
+            size = torch.zeros(1, dtype=torch.int64, device=dev)
+            d = jpegamd.Encoder.image(px.data_ptr(), img.width, img.height, img.row_stride, bool(img.bottom_up), jpegamd.ORDER_BGR, 0)
+            with torch.cuda.stream(streams[k]):
+                encs[k].encode_async(d, out.data_ptr(), cap, size.data_ptr(), True, streams[k].cuda_stream)
+            jobs.append((i, out, size))
+    torch.cuda.synchronize()
+    for e in encs:
+        e.finish()
+    expect = [oracle.encode_bmp(b) for b in bmps]
+    for n, (i, out, size) in enumerate(jobs):
+        assert bytes(out[:int(size.item())].cpu().numpy()) == expect[i], (n, shapes[i])
