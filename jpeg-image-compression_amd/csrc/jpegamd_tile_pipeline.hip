@@ -534,19 +534,21 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         {
             const uint32_t idx = cur_b0 + (uint32_t)lane;
             const bool valid = idx < cur_gt;
-            int v = (int)(short)(it & 0xFFFFu);
-            const bool isdc = (it & kItDc) != 0u;
-            if (it & kItFirst) v -= prev_dc;                 // first block of a tile: DC difference against the previous tile
-            const int run = (v && !isdc) ? (int)((it >> 16) & 0x7Fu) - (int)((itp >> 16) & 0x7Fu) - 1 : 0;   // EOB: symbol 0x00
-            const int nb = v ? (32 - __clz(abs(v))) : 0;                                          // rle.c:9-22
-            const uint32_t amp = (uint32_t)(v + (v >> 31)) & ((1u << nb) - 1u);                   // rle.c:24-35
-            const uint32_t hc = s_huff[isdc ? (256 + nb) : (((run & 15) << 4) | nb)];
+            // lanes past the end of the list code "nothing": value 0 and a table slot that holds a zero-length code
+            const uint32_t itv = valid ? it : 0u;
+            int v = (int)(short)(itv & 0xFFFFu);
+            const bool isdc = (itv & kItDc) != 0u;
+            if (itv & kItFirst) v -= prev_dc;                // first block of a tile: DC difference against the previous tile
+            const int run = (v && !isdc) ? (int)((itv >> 16) & 0x7Fu) - (int)((itp >> 16) & 0x7Fu) - 1 : 0;   // EOB: symbol 0x00
+            const int nb = 32 - __clz(abs(v));                                                     // rle.c:9-22 (clz(0) = 32)
+            const uint32_t amp = __builtin_amdgcn_ubfe((uint32_t)(v + (v >> 31)), 0u, (uint32_t)nb);   // rle.c:24-35
+            const uint32_t sym = isdc ? (uint32_t)(256 + nb) : (uint32_t)(((run & 15) << 4) | nb);
+            const uint32_t hc = s_huff[valid ? sym : 272u];
             uint32_t hi = ((hc & 0xFFFFu) << nb) | amp;
             uint32_t lo = 0;
-            int len = valid ? (int)(hc >> 16) + nb : 0;
-            const int zrl = (valid && !isdc) ? (run >> 4) : 0;                                    // rle.c:99-103
-            hi <<= (32 - len) & 31;
-            if (len == 0) hi = 0;
+            int len = (int)(hc >> 16) + nb;
+            const int zrl = isdc ? 0 : (run >> 4);                                                 // rle.c:99-103
+            hi <<= (32 - len) & 31;                          // len == 0 only with code 0 and no amplitude bits: hi is 0 already
             const bool any_zrl = __any(zrl != 0);
             if (__builtin_expect(any_zrl, 0)) {
                 const uint32_t zw = s_huff[0xF0];
