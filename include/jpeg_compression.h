@@ -158,6 +158,9 @@ int32_t jpegamd_debug_quant_consts(int32_t quality, float *mult, float *bias, fl
 
 /* Same for the matrix-pipe kernel (constants indexed by ZIGZAG position; one bias for all; delta by raster k). */
 int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, float *bias, double *delta);
+/* Zero thresholds of the split pipeline's coefficient groups ([group 0..3][lane half 0..1], group G of half h =
+ * zigzag 16G+8h .. +7): a tile whose |LUT sums| all stay below them skips that group's quantiser entirely. */
+int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr);
 
 const char *jpegamd_version(void);
 

@@ -110,6 +110,16 @@ extern "C" int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float
     return JPEGAMD_OK;
 }
 
+extern "C" int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr /*[4 groups][2 lane halves]*/) {
+    uint8_t t[64];
+    static MfmaTables mt;
+    if (!grp_thr) return JPEGAMD_ERR_ARG;
+    quant_table_for_quality(quality, t);
+    derive_mfma_tables(t, &mt, nullptr, true);
+    std::memcpy(grp_thr, mt.grp_thr, sizeof(mt.grp_thr));
+    return JPEGAMD_OK;
+}
+
 extern "C" uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return 0;
     const uint64_t nb = (uint64_t)((width + 7) / 8) * (uint64_t)((height + 7) / 8);

@@ -113,6 +113,27 @@ def test_mfma_constants_are_on_the_safe_side(jpegamd, oracle):
         assert 1e-5 < c["delta"][1:].max() < 5e-3
 
 
+def test_group_zero_thresholds_are_safe(jpegamd):
+    """Skipping a coefficient group is only legal if EVERY |LUT sum| below the threshold quantises to an unflagged 0:
+    for each site of the group, in float32 exactly as the kernel evaluates it, fl(a * qmul + bias) must stay inside
+    (qthr, 1) for a = +-threshold (monotone in a), so floor() is 0 and fract() is above the flag threshold."""
+    f32 = np.float32
+    for q in (50, 10, 90, 1, 100):
+        c = jpegamd.mfma_consts(q)
+        thr = jpegamd.group_thresholds(q)
+        bias = f32(c["bias"])
+        assert (thr > 0).all()
+        for g in range(4):
+            for h in range(2):
+                t = f32(thr[g, h])
+                for j in range(8):
+                    z = 16 * g + 8 * h + j
+                    for a in (t, -t, np.nextafter(t, f32(0)), -np.nextafter(t, f32(0))):
+                        zc = f32(np.float64(a) * np.float64(c["qmul"][z]) + np.float64(bias))      # one rounding, like v_fma_f32
+                        assert f32(c["qthr"][z]) < zc < f32(1.0), (q, g, h, j, float(a), float(zc))
+        assert thr[0].min() <= thr[3].max()                         # coarser quantisation higher up: larger zero zone
+
+
 def test_guard_band_holds_on_float32_emulation(jpegamd, oracle):
     """Emulate the kernel's fast path in numpy float32 (every op rounded separately: the worst case for
     the bound) and check against the oracle: a coefficient the guard does NOT flag must already equal the
