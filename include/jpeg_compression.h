@@ -161,6 +161,8 @@ int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, flo
 /* Zero thresholds of the split pipeline's coefficient groups ([group 0..3][lane half 0..1], group G of half h =
  * zigzag 16G+8h .. +7): a tile whose |LUT sums| all stay below them skips that group's quantiser entirely. */
 int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr);
+/* The six-decimal cosine table the kernels multiply with, [x][u] (natural_c/src/core/dct.c:9-18), for host-side emulations. */
+int32_t jpegamd_debug_cos_lut(float *lut);
 
 const char *jpegamd_version(void);
 

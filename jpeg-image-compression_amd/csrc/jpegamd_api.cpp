@@ -120,6 +120,12 @@ extern "C" int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_th
     return JPEGAMD_OK;
 }
 
+extern "C" int32_t jpegamd_debug_cos_lut(float *lut /*[8][8]: COS_LUT[x][u]*/) {
+    if (!lut) return JPEGAMD_ERR_ARG;
+    cos_lut_copy(lut);
+    return JPEGAMD_OK;
+}
+
 extern "C" uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height) {
     if (width <= 0 || height <= 0) return 0;
     const uint64_t nb = (uint64_t)((width + 7) / 8) * (uint64_t)((height + 7) / 8);

@@ -204,6 +204,7 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
                         bool grouped = false /*A-row order of the split pipeline: lane (h), site s <-> zigzag 16(s>>3)+8h+(s&7)*/);
 bool std_consts_match_baked(const uint8_t table[64]);   // table is the reference's AND baked == derived
 void build_huffman_words(uint32_t words[272]);
+void cos_lut_copy(float out[64]);              // COS_LUT[x][u] as the kernels use it (natural_c/src/core/dct.c:9-18)
 size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]);
 
 extern const uint8_t kZigzagHost[64];

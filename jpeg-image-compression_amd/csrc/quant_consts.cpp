@@ -321,6 +321,11 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
         }
 }
 
+void cos_lut_copy(float out[64]) {
+    for (int x = 0; x < 8; ++x)
+        for (int u = 0; u < 8; ++u) out[x * 8 + u] = kCosLut[x][u];
+}
+
 #include "std_table_consts.inc"
 
 bool std_consts_match_baked(const uint8_t table[64]) {

@@ -76,6 +76,7 @@ def _load() -> C.CDLL:
         "jpegamd_debug_quant_consts": (i32, [i32, vp, vp, vp, vp, vp]),
         "jpegamd_debug_mfma_consts": (i32, [i32, vp, vp, vp, vp]),
         "jpegamd_debug_group_thresholds": (i32, [i32, vp]),
+        "jpegamd_debug_cos_lut": (i32, [vp]),
         "JpegCompression_Init": (i32, []),
         "JpegCompression_DeInit": (i32, []),
         "JpegCompression_Reserve": (i32, [i32, i32]),
@@ -100,7 +101,7 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async "
             "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
-            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
+            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
             "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files "
             "jpegamd_encode_rows_async jpegamd_export_segments jpegamd_import_segments jpegamd_finalize_async").split()
@@ -131,6 +132,14 @@ def group_thresholds(quality: int = 50):
     t = np.zeros(8, np.float32)
     lib.jpegamd_debug_group_thresholds(quality, t.ctypes.data)
     return t.reshape(4, 2)
+
+
+def cos_lut():
+    """float32 [8][8]: COS_LUT[x][u] as compiled into the kernels."""
+    import numpy as np
+    t = np.zeros(64, np.float32)
+    lib.jpegamd_debug_cos_lut(t.ctypes.data)
+    return t.reshape(8, 8)
 
 
 def version() -> str:

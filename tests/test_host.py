@@ -134,6 +134,73 @@ def test_group_zero_thresholds_are_safe(jpegamd):
         assert thr[0].min() <= thr[3].max()                         # coarser quantisation higher up: larger zero zone
 
 
+def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
+    """The matrix-pipe path on the CPU: LUT-product matrix split into three bf16 terms, float32 accumulation in three
+    different orders (the hardware's order inside an MFMA is not specified; the bound is order-free), the kernel's fma
+    and flag test.  A coefficient the guard does NOT flag must equal the reference's quantised value, and the
+    observed |z_fast - z_ref| must stay below delta (random, flat, extreme and basis-aligned blocks)."""
+    f32, f64 = np.float32, np.float64
+    zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    lut = jpegamd.cos_lut()                                        # COS_LUT[x][u] as compiled into the kernels
+
+    def bf16(x):                                                   # round-to-nearest-even to bfloat16, as float64 values
+        u = np.asarray(x, f32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(f32).astype(f64)
+
+    K = np.zeros((64, 64))
+    for k in range(64):
+        u, v = divmod(k, 8)
+        K[k] = np.outer(lut[:, u].astype(f64), lut[:, v].astype(f64)).reshape(64)     # K[k][x*8+y] = LUT[x][u] * LUT[y][v]
+    hi = bf16(K); mid = bf16(K - hi); lo = bf16(K - hi - mid)
+    terms = [lo, mid, hi]                                          # small terms first, like the kernel
+    rng = np.random.default_rng(11)
+    blocks = [rng.integers(-128, 128, 64) for _ in range(150)] + [np.full(64, v) for v in (-128, 127, 3, -77)]
+    blocks += [np.where(K[k] >= 0, 127, -128) for k in (1, 9, 27, 63)] + [rng.integers(-4, 5, 64) + 100 for _ in range(20)]
+    P = np.array(blocks, dtype=np.int64)
+    ref = oracle.dct_blocks(P.reshape(-1, 8, 8).astype(np.int8)).reshape(-1, 64)
+
+    def accumulate(order):
+        acc = np.zeros((len(P), 64), f32)
+        for t in terms:
+            prod = (t[None, :, :] * P[:, None, :].astype(f64)).astype(f32)          # exact in float32: 8 x 8 significant bits
+            for s in range(4):
+                idx = list(range(16 * s, 16 * s + 16))
+                if order == "reverse":
+                    idx = idx[::-1]
+                if order == "pairwise":
+                    part = prod[:, :, idx]
+                    while part.shape[2] > 1:
+                        part = (part[:, :, 0::2] + part[:, :, 1::2]).astype(f32)
+                    acc = (acc + part[:, :, 0]).astype(f32)
+                else:
+                    for i in idx:
+                        acc = (acc + prod[:, :, i]).astype(f32)
+        return acc
+
+    for q in (50, 90):
+        c = jpegamd.mfma_consts(q)
+        table = oracle.quant_table(q).astype(f32)
+        bias = f32(c["bias"])
+        for order in ("forward", "reverse", "pairwise"):
+            acc = accumulate(order)
+            unflagged = 0
+            for z in range(64):
+                k = zz[z]
+                zc = (acc[:, k].astype(f64) * f64(c["qmul"][z]) + f64(bias)).astype(f32)      # v_fma_f32: one rounding
+                n = np.floor(zc).astype(np.int64)
+                flagged = (zc - np.floor(zc)) <= f32(c["qthr"][z])
+                want = np.array([int(np.float32(np.round(np.float32(r) / table[k]))) if abs(np.float32(r) / table[k]) % 1 != 0.5
+                                 else int(np.sign(r) * np.ceil(abs(np.float32(r) / table[k]))) for r in ref[:, k]], np.int64)   # roundf: half away
+                assert np.array_equal(n[~flagged], want[~flagged]), (q, order, z)
+                z_fast = acc[:, k].astype(f64) * f64(c["qmul"][z])
+                z_ref = ref[:, k].astype(f64) / f64(table[k])
+                assert np.abs(z_fast - z_ref).max() <= c["delta"][k], (q, order, z)
+                unflagged += int((~flagged).sum())
+            assert unflagged > 0.9 * acc.size
+
+
 def test_guard_band_holds_on_float32_emulation(jpegamd, oracle):
     """Emulate the kernel's fast path in numpy float32 (every op rounded separately: the worst case for
     the bound) and check against the oracle: a coefficient the guard does NOT flag must already equal the
