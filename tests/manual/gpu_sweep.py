@@ -6,7 +6,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "jpeg-image-compression_amd" / "python"))
 sys.path.insert(0, str(ROOT))
 import jpegamd                      # noqa: E402

@@ -2,7 +2,7 @@
 # quick parity probe + single-stream and default bench, compact output
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 120 python tools/gpu_quick.py > gpurun_out/quick.log 2>&1; tail -1 gpurun_out/quick.log
+timeout -k 10 120 python tests/manual/gpu_quick.py > gpurun_out/quick.log 2>&1; tail -1 gpurun_out/quick.log
 for s in 1 2; do
   timeout -k 10 200 python bench.py --streams $s --no-cpu-baseline > gpurun_out/bench_s$s.json 2> gpurun_out/bench_s$s.err || { tail -5 gpurun_out/bench_s$s.err; exit 1; }
   python - <<PY
