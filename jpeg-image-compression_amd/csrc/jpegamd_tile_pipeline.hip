@@ -511,26 +511,35 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     const int tprev = (lane < ntiles && tile0 + lane > 0) ? a.tile_lastdc[tile0 + lane - 1] : 0;
     uint32_t nexact = lane < ntiles ? a.tile_exact[tile0 + lane] : 0u;
 
-    // Flat walk over (tile, batch of 64 items) with the NEXT batch's two loads already in flight.
+    // Flat walk over (tile, batch of 64 items) with the NEXT batch's two loads already in flight.  The walk's state
+    // (tile, offset, count, predecessor DC, symbols of finished tiles) is wave-uniform and lives on the scalar unit.
     int ti = 0;
     uint32_t b0 = 0;
     uint32_t gt = (uint32_t)__builtin_amdgcn_readlane(tcount, 0);
+    int prev_dc_next = __builtin_amdgcn_readlane(tprev, 0);
+    uint32_t nsym_tiles = 0;                                      // uniform part of the symbol count
     const uint32_t *items = a.tile_items + (size_t)tile0 * kTileItemCap;
     uint32_t nx_itp = items[lane], nx_it = items[lane + 1];      // slot 0 = sentinel ("previous item" of the first)
 #pragma unroll 1
     while (ti < ntiles) {
         const uint32_t itp = nx_itp, it = nx_it;
         const uint32_t cur_gt = gt, cur_b0 = b0;
-        const int prev_dc = __builtin_amdgcn_readlane(tprev, ti);
+        const int prev_dc = prev_dc_next;
         // advance and request
         b0 += 64;
         if (b0 >= gt) {
-            nsym += (lane == 0) ? (int)gt : 0;
+            nsym_tiles += gt;
             ++ti;
             b0 = 0;
-            if (ti < ntiles) { gt = (uint32_t)__builtin_amdgcn_readlane(tcount, ti); items += kTileItemCap; }
+            if (ti < ntiles) {
+                gt = (uint32_t)__builtin_amdgcn_readlane(tcount, ti);
+                prev_dc_next = __builtin_amdgcn_readlane(tprev, ti);
+                items += kTileItemCap;
+            }
         }
-        if (ti < ntiles) { nx_itp = items[b0 + lane]; nx_it = items[b0 + lane + 1]; }   // past-the-list reads stay inside the reservation
+        // unconditional: after the last batch this re-reads the head of the last tile's list (inside the reservation, unused)
+        nx_itp = items[b0 + lane];
+        nx_it = items[b0 + lane + 1];
         {
             const uint32_t idx = cur_b0 + (uint32_t)lane;
             const bool valid = idx < cur_gt;
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         if ((carry_bits & 31u) && lane == 0) segw[wbase] = part;
         if (lane == 0) win[0] = part;
     }
-    const int seg_syms = wave_sum_i32(nsym);
+    const int seg_syms = wave_sum_i32(nsym) + (int)nsym_tiles;
     const int seg_exact = wave_sum_i32((int)nexact);
     if (lane == 0) {
         const uint32_t p = carry_bits & 31u, w0 = win[0];
