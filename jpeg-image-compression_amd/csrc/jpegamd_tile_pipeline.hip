@@ -518,8 +518,13 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     uint32_t gt = (uint32_t)__builtin_amdgcn_readlane(tcount, 0);
     int prev_dc_next = __builtin_amdgcn_readlane(tprev, 0);
     uint32_t nsym_tiles = 0;                                      // uniform part of the symbol count
-    const uint32_t *items = a.tile_items + (size_t)tile0 * kTileItemCap;
-    uint32_t nx_itp = items[lane], nx_it = items[lane + 1];      // slot 0 = sentinel ("previous item" of the first)
+    // the segment's lists through one buffer descriptor: scalar offset = tile and batch, lane offset = 4 * lane
+    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(a.tile_items + (size_t)tile0 * kTileItemCap), 0, ntiles * kTileItemCap * 4, 0x00020000);
+    const int lane4 = lane * 4;
+    uint32_t soff = 0;                                            // byte offset of the current tile's list
+    uint32_t nx_itp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4, 0, 0);       // slot 0 = sentinel ("previous item" of the first)
+    uint32_t nx_it = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4 + 4, 0, 0);
 #pragma unroll 1
     while (ti < ntiles) {
         const uint32_t itp = nx_itp, it = nx_it;
@@ -534,12 +539,12 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
             if (ti < ntiles) {
                 gt = (uint32_t)__builtin_amdgcn_readlane(tcount, ti);
                 prev_dc_next = __builtin_amdgcn_readlane(tprev, ti);
-                items += kTileItemCap;
+                soff += (uint32_t)kTileItemCap * 4u;
             }
         }
-        // unconditional: after the last batch this re-reads the head of the last tile's list (inside the reservation, unused)
-        nx_itp = items[b0 + lane];
-        nx_it = items[b0 + lane + 1];
+        // unconditional: after the last batch this re-reads the head of the last tile's list (inside the descriptor, unused)
+        nx_itp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4, (int)(soff + b0 * 4u), 0);
+        nx_it = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4 + 4, (int)(soff + b0 * 4u), 0);
         {
             const uint32_t idx = cur_b0 + (uint32_t)lane;
             const bool valid = idx < cur_gt;
