@@ -48,8 +48,7 @@ struct JpegAmdEncoder {
     MfmaTables *tables_dev = nullptr;
     uint8_t *seg_tail = nullptr;                // last 7 bits of every segment (matrix-pipe kernel)
     bool split_pipeline = true;                 // tile transform + entropy kernels (JPEGAMD_KERNEL=mfma-fused: one kernel)
-    uint32_t *tile_items = nullptr, *tile_count = nullptr, *tile_exact = nullptr, *tile_ctr = nullptr;
-    int32_t *tile_lastdc = nullptr;
+    uint32_t *tile_items = nullptr, *tile_ctr = nullptr;
     int max_tiles = 0;
     uint32_t *chunk_ff = nullptr;               // finalize kernels: per-chunk 0xFF totals and bit offsets
     unsigned long long *chunk_b0 = nullptr;
@@ -177,11 +176,8 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY(hipMalloc((void **)&e->seg_tail, (size_t)e->max_segs + 16));
     e->max_tiles = ((max_height + 7) / 8) * (((max_width + 7) / 8 + kTileBlocks - 1) / kTileBlocks);
     HIP_TRY(hipMalloc((void **)&e->tile_items, (size_t)e->max_tiles * kTileItemCap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->tile_count, (size_t)e->max_tiles * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->tile_exact, (size_t)e->max_tiles * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->tile_ctr, 64 * 128));          // kTileGroups cache lines
     HIP_TRY(hipMemset(e->tile_ctr, 0, 64 * 128));
-    HIP_TRY(hipMalloc((void **)&e->tile_lastdc, (size_t)e->max_tiles * sizeof(int32_t)));
     HIP_TRY(hipMalloc((void **)&e->chunk_ff, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&e->chunk_b0, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(unsigned long long)));
     if (const char *post = std::getenv("JPEGAMD_POST")) e->use_finalize = std::strcmp(post, "split") != 0;
@@ -209,7 +205,7 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (e->pending) hipStreamSynchronize(e->last_stream);
     free_scratch(e);
     hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev); hipFree(e->chunk_ff); hipFree(e->chunk_b0); hipFree(e->seg_tail);
-    hipFree(e->tile_items); hipFree(e->tile_count); hipFree(e->tile_exact); hipFree(e->tile_lastdc); hipFree(e->tile_ctr);
+    hipFree(e->tile_items); hipFree(e->tile_ctr);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e;
     return JPEGAMD_OK;
@@ -334,12 +330,12 @@ static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool tap
             if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
             return err;
         }
-        to.tile_items = e->tile_items; to.tile_count = e->tile_count; to.tile_lastdc = e->tile_lastdc; to.tile_exact = e->tile_exact; to.tile_ctr = e->tile_ctr;
+        to.tile_items = e->tile_items; to.tile_ctr = e->tile_ctr;
         if (int err = launch_tile_transform(im, to, taps, stream)) return err;
         if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
         EntropyArgs ea;
         std::memset(&ea, 0, sizeof(ea));
-        ea.tile_items = e->tile_items; ea.tile_count = e->tile_count; ea.tile_exact = e->tile_exact; ea.tile_lastdc = e->tile_lastdc;
+        ea.tile_items = e->tile_items;
         ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
         ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
         ea.seg_words = e->seg_words; ea.seg_bits = e->seg_bits; ea.seg_syms = e->seg_syms; ea.seg_exact = e->seg_exact;

@@ -49,6 +49,8 @@ constexpr int kSegCapWordsM = ((kSegBlocksM * kMaxBlockBits + 31) / 32 + 1 + 63)
 constexpr int kAFragWords = 3 * 2 * 4 * 64 * 4;      // [term][chain][kstep][lane] x 8 bf16 = 24 KiB
 // split pipeline (jpegamd_tile_pipeline.hip): per-tile symbol lists in HBM; slot 0 is a sentinel, 64 words of read slack
 constexpr int kTileItemCap = (1 + kTileBlocks * 65 + 64 + 63) / 64 * 64;   // 2176
+constexpr int kTileRecord = kTileItemCap - 4;   // the list's last 4 words: {items, DC of the last block, exact-path count, 0}, one 16-byte store
+static_assert(1 + kTileBlocks * 65 + 64 <= kTileRecord, "the per-tile record must lie behind the longest list and its read-ahead");
 
 struct MfmaTables {
     uint32_t afrag[kAFragWords];   // LUT-product matrix, 3-way bf16 split (lo, mid, hi), MFMA A-operand order
@@ -172,11 +174,8 @@ struct TransformOutM {          // like TransformOut, for the matrix-pipe kernel
     const MfmaTables *tables;   // device copy
     unsigned long long *stamps; // [num_segs][16] per-phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
     // split pipeline only: per-tile outputs of k_tile_transform
-    uint32_t *tile_items;       // [num_tiles][kTileItemCap]
+    uint32_t *tile_items;       // [num_tiles][kTileItemCap]: word 0 sentinel, items from word 1, per-tile record at kTileRecord
     uint32_t *tile_ctr;         // [64 groups][32 words]: word 0 ticket counter of the dynamic tile hand-out, word 1 waves finished; zero between launches
-    uint32_t *tile_count;       // [num_tiles] items in the list
-    int32_t *tile_lastdc;       // [num_tiles] quantised DC of the tile's last block
-    uint32_t *tile_exact;       // [num_tiles] coefficients recomputed in exact order
     FinReset reset;             // cleared by workgroup 0
     int8_t *tap_y;
     int16_t *tap_zz;
@@ -185,8 +184,7 @@ struct TransformOutM {          // like TransformOut, for the matrix-pipe kernel
 int launch_transform_mfma(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream);
 int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream);
 struct EntropyArgs {            // k_entropy: per-tile symbol lists -> per-segment bit strings
-    const uint32_t *tile_items, *tile_count, *tile_exact;
-    const int32_t *tile_lastdc;
+    const uint32_t *tile_items;     // [num_tiles][kTileItemCap]: sentinel, items, ..., record at kTileRecord
     const uint32_t *huff;
     int32_t num_segs, segs_per_row, tiles_per_row;
     int32_t seg_begin, seg_end;     // segments this launch codes (whole image: 0, num_segs)

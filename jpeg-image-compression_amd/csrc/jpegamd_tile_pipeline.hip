@@ -437,9 +437,8 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
         if (lane == 0) {
             list[0] = 0u;
-            out.tile_count[tile] = t_all;
-            out.tile_lastdc[tile] = __builtin_amdgcn_readlane(n[0], nblk - 1);
-            out.tile_exact[tile] = (uint32_t)nexact;
+            *reinterpret_cast<uint4 *>(list + kTileRecord) =
+                make_uint4(t_all, (uint32_t)__builtin_amdgcn_readlane(n[0], nblk - 1), (uint32_t)nexact, 0u);
         }
 #undef JPEGAMD_ACC
         TSTAMP(7);   // appends
@@ -507,9 +506,11 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
 #pragma unroll
     for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
     // everything whose address is known up front is requested now: counts and predecessor DCs of the segment's tiles
-    const int tcount = lane < ntiles ? (int)a.tile_count[tile0 + lane] : 0;
-    const int tprev = (lane < ntiles && tile0 + lane > 0) ? a.tile_lastdc[tile0 + lane - 1] : 0;
-    uint32_t nexact = lane < ntiles ? a.tile_exact[tile0 + lane] : 0u;
+    const uint32_t *trec = a.tile_items + (size_t)(tile0 + lane) * kTileItemCap + kTileRecord;      // {items, last DC, exact count, 0}
+    const uint4 rec = lane < ntiles ? *reinterpret_cast<const uint4 *>(trec) : make_uint4(0u, 0u, 0u, 0u);
+    const int tcount = (int)rec.x;
+    const int tprev = (lane < ntiles && tile0 + lane > 0) ? (int)trec[1 - kTileItemCap] : 0;       // the tile before: its last DC
+    uint32_t nexact = rec.z;
 
     // Flat walk over (tile, batch of 64 items) with the NEXT batch's two loads already in flight.  The walk's state
     // (tile, offset, count, predecessor DC, symbols of finished tiles) is wave-uniform and lives on the scalar unit.
