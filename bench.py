@@ -43,8 +43,8 @@ ROTATE = 3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--width", type=int, default=8192)
     ap.add_argument("--height", type=int, default=8192)
     ap.add_argument("--kind", type=int, default=0, help="synthetic content: 0 photo-like, 1 noise, 2 flat, 3 gradient")
