@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, PKG, fixture_bmp, golden_jpg
+from conftest import GOLDEN, PKG, ROOT, fixture_bmp, golden_jpg
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -395,3 +395,22 @@ def test_concurrent_streams_and_contexts(jpegamd, oracle, dev):
     expect = [oracle.encode_bmp(b) for b in bmps]
     for n, (i, out, size) in enumerate(jobs):
         assert bytes(out[:int(size.item())].cpu().numpy()) == expect[i], (n, shapes[i])
+
+
+@pytest.mark.gpu
+def test_reference_main_linked_against_the_library(jpegamd, oracle, dev, tmp_path):
+    """INTEGRATION.md section 1 as an executable: the reference's UNMODIFIED natural_c/src/main.c, compiled against the
+    reference's own headers and linked with libjpegamd.so instead of its src/core + src/io (oracle/Makefile `ref`),
+    writes the same bytes as the reference and keeps main.c's exit codes."""
+    app = ROOT / "oracle" / "_ref" / "main_on_jpegamd"
+    if not app.exists():
+        pytest.skip("oracle/_ref/main_on_jpegamd not built (needs the reference sources at build time)")
+    for i, (w, h, kind, flags) in enumerate([(320, 200, 0, 0), (203, 117, 1, 1), (333, 250, 0, 2)]):
+        bmp = jpegamd.synth_bmp(w, h, 70 + i, kind, flags)
+        src, dst = tmp_path / f"in{i}.bmp", tmp_path / f"out{i}.jpg"
+        src.write_bytes(bmp)
+        r = subprocess.run([str(app), str(src), str(dst)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert dst.read_bytes() == oracle.encode_bmp(bmp), (w, h, kind, flags)
+    assert subprocess.run([str(app)], capture_output=True, timeout=60).returncode == 1                       # main.c:9-12
+    assert subprocess.run([str(app), str(tmp_path / "missing.bmp"), str(tmp_path / "x.jpg")], capture_output=True, timeout=60).returncode == 1   # main.c:29-31
