@@ -414,3 +414,19 @@ def test_reference_main_linked_against_the_library(jpegamd, oracle, dev, tmp_pat
         assert dst.read_bytes() == oracle.encode_bmp(bmp), (w, h, kind, flags)
     assert subprocess.run([str(app)], capture_output=True, timeout=60).returncode == 1                       # main.c:9-12
     assert subprocess.run([str(app), str(tmp_path / "missing.bmp"), str(tmp_path / "x.jpg")], capture_output=True, timeout=60).returncode == 1   # main.c:29-31
+
+
+@pytest.mark.gpu
+def test_reference_driver_over_the_gpu_stage_functions(jpegamd, oracle, dev, tmp_path):
+    """The reference's own driver (main.c + io/jpeg_handler.c + io/bmp_handler.c, unmodified) with every stage function
+    resolved from libjpegamd.so (natural_c_stages.h): the bytes it writes equal the reference's."""
+    app = ROOT / "oracle" / "_ref" / "driver_on_jpegamd_stages"
+    if not app.exists():
+        pytest.skip("oracle/_ref/driver_on_jpegamd_stages not built (needs the reference sources at build time)")
+    for i, (w, h, kind, flags) in enumerate([(200, 120, 0, 0), (203, 117, 1, 1)]):
+        bmp = jpegamd.synth_bmp(w, h, 80 + i, kind, flags)
+        src, dst = tmp_path / f"in{i}.bmp", tmp_path / f"out{i}.jpg"
+        src.write_bytes(bmp)
+        r = subprocess.run([str(app), str(src), str(dst)], capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stderr
+        assert dst.read_bytes() == oracle.encode_bmp(bmp), (w, h, kind, flags)
