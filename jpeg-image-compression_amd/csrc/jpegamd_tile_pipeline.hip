@@ -102,6 +102,9 @@ constexpr int kTileGroups = 64;                 // ticket counters (one cache li
 #ifndef JPEGAMD_TILE_WAVES
 #define JPEGAMD_TILE_WAVES 4
 #endif
+#ifndef JPEGAMD_TILE_INTERLEAVE
+#define JPEGAMD_TILE_INTERLEAVE 1
+#endif
 
 struct TileSched {            // division-free launch geometry, filled by launch_tile_transform
     int32_t grp_shift;        // workgroups form 1 << grp_shift ticket groups (blockIdx & mask)
@@ -123,6 +126,10 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
     // prefetched rows of the NEXT tile as well: ~40 % of a tile's time per event (tools/stamp_profile_tile.py).
     __shared__ __attribute__((aligned(16))) uint32_t s_pix[kWavesT][8 * 132];
+#ifdef JPEGAMD_STAMPS
+    unsigned long long st_rt0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
+#endif
 
     {
         const int t = (int)threadIdx.x;
@@ -158,8 +165,23 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     const int groups = 1 << sch.grp_shift;
     const int grp = (int)blockIdx.x & (groups - 1);
     const int grp_waves = ((((int)gridDim.x - 1 - grp) >> sch.grp_shift) + 1) * kWavesT;   // waves of this group
+#if JPEGAMD_TILE_INTERLEAVE
+    // A group owns the CHUNKS (kWavesT consecutive tiles, what its 8 waves work on side by side) c = grp, grp + groups, ...
+    // and walks them in order: content density varies slowly over the picture, so contiguous ranges per group left
+    // the densest group 10-20 % behind the mean (profiles/r02_stamps_r01_kernel.txt: workgroup means 77 k .. 92 k cycles).
+    // Below, grp_lo / grp_hi / tile indices of the loop are GROUP-LOCAL; to_tile() maps them to picture tiles.
+    const int ntl = im.tile_end - im.tile_begin;
+    const int nchunks = (ntl + kWavesT - 1) / kWavesT;
+    const int my_chunks = grp < nchunks ? ((nchunks - 1 - grp) >> sch.grp_shift) + 1 : 0;
+    const bool owns_last = my_chunks > 0 && ((nchunks - 1) & (groups - 1)) == grp;
+    const int grp_lo = 0;
+    const int grp_hi = my_chunks * kWavesT - (owns_last ? nchunks * kWavesT - ntl : 0);
+    const auto to_tile = [&](int li) { return im.tile_begin + ((((li / kWavesT) << sch.grp_shift) + grp) * kWavesT) + (li % kWavesT); };
+#else
     const int grp_lo = min(im.tile_begin + grp * sch.tiles_per_group, im.tile_end);
     const int grp_hi = min(grp_lo + sch.tiles_per_group, im.tile_end);
+    const auto to_tile = [&](int li) { return li; };
+#endif
     uint32_t *ctr = out.tile_ctr + grp * 32;                                                // [0] tickets, [1] waves done
     const int first = grp_lo + ((int)blockIdx.x >> sch.grp_shift) * kWavesT + wave;
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
@@ -191,18 +213,20 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
     };
     RawRow raw[4];
-    TileGeo tg = geo(first < grp_hi ? first : 0);
+    TileGeo tg = geo(first < grp_hi ? to_tile(first) : im.tile_begin);
 #if JPEGAMD_TILE_PREFETCH
     if (first < grp_hi && tg.interior) request_rows(tg, raw);
 #endif
     int nxt = first < grp_hi ? grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket()) : grp_hi;
 #ifdef JPEGAMD_STAMPS
-    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_last)::"memory");
+    const unsigned long long st_c1 = st_last;
 #endif
 
 #pragma unroll 1
-    for (int tile = first; tile < grp_hi;) {
+    for (int li = first; li < grp_hi;) {
+        const int tile = to_tile(li);
         const uint32_t ticket_v = ticket();                   // consumed at the bottom of the iteration
         const int by = tg.by, nblk = tg.nblk, bx = tg.bx;
         const int py0 = by * 8, px0 = bx * 8;
@@ -228,9 +252,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         TSTAMP(1);   // wait for the prefetched rows + luma
         TileGeo tg_next = tg;                                 // one division per tile: the geometry is carried over
 #if JPEGAMD_TILE_PREFETCH == 1
-        if (nxt < grp_hi) { tg_next = geo(nxt); if (tg_next.interior) request_rows(tg_next, raw); }
+        if (nxt < grp_hi) { tg_next = geo(to_tile(nxt)); if (tg_next.interior) request_rows(tg_next, raw); }
 #else
-        if (nxt < grp_hi) tg_next = geo(nxt);
+        if (nxt < grp_hi) tg_next = geo(to_tile(nxt));
 #endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x8 *>(&s_pix[wave][(2 * s + h) * 132 + b * 4]) = bfrag[s];
@@ -442,7 +466,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
 #undef JPEGAMD_ACC
         TSTAMP(7);   // appends
-        tile = nxt;
+        li = nxt;
         tg = tg_next;
         nxt = nxt_ticket;
     }
@@ -452,7 +476,15 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         ctr[1] = 0u;
     }
 #ifdef JPEGAMD_STAMPS
-    if (lane == 0 && out.stamps) for (int i = 0; i < 10; ++i) out.stamps[(size_t)(blockIdx.x * kWavesT + wave) * 16 + i] = st_sum[i];
+    {   // [8] kernel entry, [9] loop start, [10] loop end in 100 MHz ticks; [11] shader cycles of the loop
+        unsigned long long st_rt2, st_c2;
+        asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt2), "=s"(st_c2)::"memory");
+        if (lane == 0 && out.stamps) {
+            unsigned long long *o = out.stamps + (size_t)(blockIdx.x * kWavesT + wave) * 16;
+            for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
+            o[8] = st_rt0; o[9] = st_rt1; o[10] = st_rt2; o[11] = st_c2 - st_c1;
+        }
+    }
 #endif
 }
 

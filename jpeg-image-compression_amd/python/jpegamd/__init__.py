@@ -11,7 +11,8 @@ import os
 from pathlib import Path
 
 _PKG_ROOT = Path(__file__).resolve().parents[2]          # .../jpeg-image-compression_amd
-LIB_PATH = _PKG_ROOT / "libjpegamd.so"
+# JPEGAMD_LIB: A/B tooling only (tools/gpu_*.sh point it at a variant build of the same library)
+LIB_PATH = Path(os.environ.get("JPEGAMD_LIB") or (_PKG_ROOT / "libjpegamd.so"))
 HEADER_PATH = _PKG_ROOT.parent / "include" / "jpeg_compression.h"
 
 ORDER_BGR, ORDER_RGB = 0, 1

@@ -202,18 +202,94 @@ def test_large_configs_against_reference_hashes(jpegamd, dev):
     reference wrote for the same deterministic input (tests/golden/large.json)."""
     large = json.loads((GOLDEN / "large.json").read_text())
     enc = jpegamd.Encoder(8192, 8192)
-    for key, e in large.items():
-        dims, seed, kind, _ = key.split("_")
+    assert {"8192x8192_seed1000_kind0_q10", "8192x8192_seed1000_kind0_q90", "8192x8192_seed1000_kind1_q50"} <= set(large)
+    for key, e in large.items():                       # configs[1], [2], [4] (Q = 10 / 50 / 90 on 8192^2) and the noise stress
+        dims, seed, kind, q = key.split("_")
         w, h = (int(x) for x in dims.split("x"))
         bmp = jpegamd.synth_bmp(w, h, int(seed[4:]), int(kind[4:]), 0)
         assert hashlib.sha256(bmp).hexdigest() == e["bmp_sha256"]
-        got, st = device_encode(jpegamd, enc, bmp, dev, cap=4096 + w * h)
+        got, st = device_encode(jpegamd, enc, bmp, dev, quality=int(q[1:]), cap=4096 + 2 * w * h)
         assert (len(got), hashlib.sha256(got).hexdigest()) == (e["size"], e["sha256"]), key
         # size-independent properties of the stream
         assert got[:2] == b"\xff\xd8" and got[-2:] == b"\xff\xd9"
         body = got[328:-2]
         assert b"\xff" not in body.replace(b"\xff\x00", b""), "an unstuffed 0xFF inside the entropy-coded segment"
         assert st.entropy_bits > 0 and (st.entropy_bits + 7) // 8 + st.stuffed_bytes == len(body)
+
+
+def test_reference_sample_images(jpegamd, dev):
+    """The reference's own assets/input/*.bmp (512x512 lena / blackbuck = BASELINE configs[0]'s input, greenland 762x1309,
+    offset_sample with bfOffBits = 138) through the HIP path: sha256 == what the compiled reference wrote."""
+    answers = json.loads((GOLDEN / "assets.json").read_text())
+    assert len(answers) == 4
+    for name, e in answers.items():
+        bmp = (GOLDEN / "assets" / name).read_bytes()
+        assert hashlib.sha256(bmp).hexdigest() == e["bmp_sha256"], name
+        got = jpegamd.encode_bmp_bytes(bmp)
+        assert (len(got), hashlib.sha256(got).hexdigest()) == (e["jpg_size"], e["jpg_sha256"]), name
+    assert answers["lena.bmp"]["jpg_sha256"].startswith("95cf58fe")
+
+
+def test_batch_of_64_4096_through_the_gather_path(jpegamd, dev):
+    """BASELINE configs[3] at its stated shape on one GPU: 64 distinct 4096x4096 images encoded straight into the
+    records of jpegamd.sharding.BatchedStreamGather (a one-rank RCCL group: the collective degenerates to a copy, the
+    code path is the N > 1 one of bench.py), every gathered stream hashed against the compiled reference's answer."""
+    import os
+    import torch.distributed as dist
+    from jpegamd.sharding import BatchedStreamGather
+    batch = json.loads((GOLDEN / "batch4096.json").read_text())
+    seeds = sorted(int(k.split("_")[1][4:]) for k in batch)
+    assert len(seeds) == 64
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    own_group = not dist.is_initialized()
+    if own_group:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        w = h = 4096
+        G, nstreams = 32, 2
+        biggest = max(e["size"] for e in batch.values())
+        slot_bytes = ((biggest * 21 // 20 + 4096 + 255) // 256) * 256 + 8
+        gather = BatchedStreamGather(slot_bytes, G, dev, dst=0, depth=2)
+        encs = [jpegamd.Encoder(w, h) for _ in range(nstreams)]
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        stride = 3 * w
+        keep, got = [], {}
+        for i, seed in enumerate(seeds):
+            bmp = jpegamd.synth_bmp(w, h, seed, 0, 0)
+            assert hashlib.sha256(bmp).hexdigest() == batch[f"4096x4096_seed{seed}_kind0_q50"]["bmp_sha256"]
+            px = torch.frombuffer(bytearray(bmp[54:54 + stride * h]), dtype=torch.uint8).to(dev)
+            keep.append(px)
+            si = i % nstreams
+            with torch.cuda.stream(streams[si]):
+                streams[si].wait_stream(torch.cuda.current_stream())          # the upload ran on the default stream
+                if i % G < nstreams:
+                    gather.reserve(i)
+                pl, sz = gather.record(i)
+                d = jpegamd.Encoder.image(px.data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, 0)
+                encs[si].encode_async(d, pl.data_ptr(), pl.numel(), sz.data_ptr(), True, streams[si].cuda_stream)
+                if i % G == G - 1:
+                    for sj in streams:
+                        if sj != streams[si]:
+                            streams[si].wait_event(sj.record_event())
+                    gather.commit(i)
+            if i % G == G - 1:
+                gather.wait_all()
+                torch.cuda.synchronize()
+                per_rank = gather.result(i)
+                assert len(per_rank) == 1 and len(per_rank[0]) == G
+                for k, sbytes in enumerate(per_rank[0]):
+                    got[seeds[i - G + 1 + k]] = (len(sbytes), hashlib.sha256(sbytes).hexdigest())
+                keep.clear()
+        for e in encs:
+            e.finish()
+        assert gather.collectives == 2
+        for seed in seeds:
+            e = batch[f"4096x4096_seed{seed}_kind0_q50"]
+            assert got[seed] == (e["size"], e["sha256"]), seed
+    finally:
+        if own_group:
+            dist.destroy_process_group()
 
 
 def test_repeatable_and_order_independent(jpegamd, dev):

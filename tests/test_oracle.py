@@ -42,11 +42,25 @@ def test_large_golden_1080p(oracle, jpegamd):
     assert (len(got), hashlib.sha256(got).hexdigest()) == (e["size"], e["sha256"])
 
 
-@pytest.mark.skipif(not (REF / "assets" / "input").exists(), reason="reference assets only exist in the build container")
+def test_batch4096_golden_sample(oracle, jpegamd):
+    """BASELINE configs[3] (64 x 4096^2): the restatement against the compiled reference's answer for two of the 64 seeds
+    (the GPU suite hashes all 64 through the gather path)."""
+    batch = json.loads((GOLDEN / "batch4096.json").read_text())
+    assert len(batch) == 64 and len({e["sha256"] for e in batch.values()}) == 64
+    for seed in (2000, 2063):
+        e = batch[f"4096x4096_seed{seed}_kind0_q50"]
+        bmp = jpegamd.synth_bmp(4096, 4096, seed, 0, 0)
+        assert hashlib.sha256(bmp).hexdigest() == e["bmp_sha256"]
+        got = oracle.encode_bmp(bmp)
+        assert (len(got), hashlib.sha256(got).hexdigest()) == (e["size"], e["sha256"]), seed
+
+
 def test_reference_assets_known_answers(oracle):
+    """The reference's own four sample images (tests/golden/assets: data fixtures) -> SURVEY.md 8c known answers."""
     answers = json.loads((GOLDEN / "assets.json").read_text())
     for name, e in answers.items():
-        bmp = (REF / "assets" / "input" / name).read_bytes()
+        bmp = (GOLDEN / "assets" / name).read_bytes()
+        assert hashlib.sha256(bmp).hexdigest() == e["bmp_sha256"], name
         got = oracle.encode_bmp(bmp)
         assert (len(got), hashlib.sha256(got).hexdigest()) == (e["jpg_size"], e["jpg_sha256"]), name
     # SURVEY.md 8c known answers

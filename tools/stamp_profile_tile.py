@@ -46,3 +46,12 @@ for i, n in enumerate(names):
     print(f"  {n:18s} std {col.std():8.0f}  p99 {np.percentile(col, 99):8.0f}  max {col.max():8.0f}")
 ex = buf[:, 5].astype(np.float64)
 print("corr(total, exact) =", np.corrcoef(tw.reshape(-1), ex)[0, 1], " corr(total, appends) =", np.corrcoef(tw.reshape(-1), buf[:, 7].astype(np.float64))[0, 1])
+
+rt = buf[:, 8:11].astype(np.float64)
+span = (rt[:, 2].max() - rt[:, 0].min()) / 100.0
+print(f"kernel span seen by the waves: {span:.2f} us; entry spread {(rt[:, 0].max() - rt[:, 0].min()) / 100.0:.2f} us; "
+      f"prologue (entry -> loop) mean {(rt[:, 1] - rt[:, 0]).mean() / 100.0:.2f} us max {(rt[:, 1] - rt[:, 0]).max() / 100.0:.2f} us; "
+      f"loop mean {(rt[:, 2] - rt[:, 1]).mean() / 100.0:.2f} us max {(rt[:, 2] - rt[:, 1]).max() / 100.0:.2f} us; "
+      f"first wave done at {(rt[:, 2].min() - rt[:, 0].min()) / 100.0:.2f} us")
+clk = buf[:, 11].astype(np.float64) / np.maximum(rt[:, 2] - rt[:, 1], 1.0) * 0.1
+print(f"shader clock inside the loop: mean {clk.mean():.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})")
