@@ -150,13 +150,11 @@ int32_t jpegamd_debug_dct_exact(JpegAmdEncoder *enc, const int8_t *blocks, float
 uint64_t jpegamd_synth_bmp(int32_t width, int32_t height, uint32_t seed, int32_t kind,
                            uint32_t flags, uint8_t *out, uint64_t cap);
 
-/* Host-only introspection for tests: the per-coefficient fast-path constants the kernel would
- * use for `quality` (raster order, 64 each): scale M_k, bias (0.5 + delta_k), threshold
- * (2*delta_k) and the rigorous guard band delta_k itself.  Any pointer may be NULL. */
-int32_t jpegamd_debug_quant_consts(int32_t quality, float *mult, float *bias, float *thr, double *delta,
-                                   uint8_t *table);
+/* Host-only introspection for tests.  The quantisation table for `quality` (raster order; 50 = the reference's,
+ * natural_c/src/core/jpeg_tables.c:3-12; other values = its libjpeg scaling, an extension). */
+int32_t jpegamd_debug_quant_table(int32_t quality, uint8_t *table);
 
-/* Same for the matrix-pipe kernel (constants indexed by ZIGZAG position; one bias for all; delta by raster k). */
+/* Constants of the fast quantiser, indexed by ZIGZAG position (one bias for all; the rigorous guard band delta by raster k). */
 int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, float *bias, double *delta);
 /* Zero thresholds of the split pipeline's coefficient groups ([group 0..3][lane half 0..1], group G of half h =
  * zigzag 16G+8h .. +7): a tile whose |LUT sums| all stay below them skips that group's quantiser entirely. */
@@ -261,12 +259,14 @@ int64_t jpegamd_encode_bmp_memory(const uint8_t *bmp, uint64_t bmp_len, int32_t 
  * jpegamd_encode_rows_async for its block rows [begin, end) of the SAME image description
  * (it needs the pixel rows of its range and of the one block row above); the unstuffed
  * per-segment bit strings stay in its context.  jpegamd_export_segments packs them densely:
- * `dense_words` (used 32-bit words of the range's segments, back to back), `meta` (8 uint32 per
- * segment: bits, word offset, tail bits, symbols, exact-path count, 0, 0, 0) and the word total.
+ * `dense_words` (used 32-bit words of the range's segments, back to back), `meta`
+ * (jpegamd_segment_meta_words() = 12 uint32 per segment: bits, word offset, first 8 / last 7 bits, symbols,
+ * exact-path count, 0, 0, 0, and the counts of 0xFF bytes inside the segment for the 8 byte phases) and the word total.
  * After moving both buffers to the root (RCCL), jpegamd_import_segments places them at their
  * global segment indices in the root's context, and jpegamd_finalize_async stitches all
  * segments: bit offsets, 0xFF stuffing and the zero-padded flush happen once, there.
- * All four are stream-ordered; errors as jpegamd_encode_async; split pipeline only. */
+ * All four are stream-ordered; errors as jpegamd_encode_async. */
+int32_t jpegamd_segment_meta_words(void);
 int32_t jpegamd_encode_rows_async(JpegAmdEncoder *enc, const JpegAmdImage *img, int32_t block_row_begin,
                                   int32_t block_row_end, void *stream);
 int32_t jpegamd_export_segments(JpegAmdEncoder *enc, const JpegAmdImage *img, int32_t block_row_begin,

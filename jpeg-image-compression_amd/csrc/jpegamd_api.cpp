@@ -1,6 +1,6 @@
 // jpegamd_api.cpp -- C-ABI host layer over the HIP kernels (include/jpeg_compression.h).
 //
-// Level 1 (jpegamd_*): device-resident, stream-ordered encode.
+// Level 1 (jpegamd_*): device-resident, stream-ordered encode: k_tile_transform -> k_entropy -> k_finalize.
 // Level 2 (JpegCompression_Init / convertToJpeg): the reference's accelerator boundary
 //          (dsp_port/jpeg_compression/src/jpeg_compression.c:6-33,35-216).
 // There is no CPU fallback: without a HIP device every compute entry fails.
@@ -30,33 +30,20 @@ using namespace jpegamd;
 
 struct JpegAmdEncoder {
     int device = -1;
-    int max_w = 0, max_h = 0, max_segs = 0;      // max_segs: 64-block segments (sizes the per-segment arrays)
-    int max_segs_m = 0;                          // 256-block segments of the matrix-pipe kernels (sizes seg_words with kSegCapWordsM)
-    // device scratch
-    uint32_t *seg_words = nullptr, *seg_bits = nullptr, *seg_syms = nullptr, *seg_exact = nullptr;
-    uint32_t *seg_ff = nullptr, *ovf_words = nullptr, *huff = nullptr;
-    uint64_t *seg_bitstart = nullptr, *seg_ffstart = nullptr;
+    int max_w = 0, max_h = 0, max_segs = 0, max_tiles = 0;
+    // device scratch, sized once for max_w x max_h
+    SegArrays seg = {};
+    uint32_t *huff = nullptr;
     uint8_t *prefix = nullptr;
     ScanStats *stats_dev = nullptr;
     ScanStats mirror;            // host copy of stats_dev, fetched by finish()
+    MfmaTables *tables_dev = nullptr;
+    MfmaTables *tables_host = nullptr;          // this context's own staging copy (contexts may be driven from different threads)
+    uint32_t *tile_items = nullptr, *tile_ctr = nullptr;
+    unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
     // cached constants
     int cur_quality = -1;
-    bool std_kernel = false;     // table == reference's and baked literals == derived constants
-    int entropy_backend = 1;     // 1 = symbol-parallel (default), 0 = per-lane loop (JPEGAMD_ENTROPY=lane)
-    bool use_mfma = true;        // matrix-pipe transform kernel (JPEGAMD_KERNEL=aan|generic selects the register AAN kernel)
-    bool force_generic = false;  // JPEGAMD_KERNEL=generic: AAN kernel with run-time constants even for the reference table
-    MfmaTables *tables_dev = nullptr;
-    uint8_t *seg_tail = nullptr;                // last 7 bits of every segment (matrix-pipe kernel)
-    bool split_pipeline = true;                 // tile transform + entropy kernels (JPEGAMD_KERNEL=mfma-fused: one kernel)
-    uint32_t *tile_items = nullptr, *tile_ctr = nullptr;
-    int max_tiles = 0;
-    uint32_t *chunk_ff = nullptr;               // finalize kernels: per-chunk 0xFF totals and bit offsets
-    unsigned long long *chunk_b0 = nullptr;
-    bool use_finalize = true;                   // JPEGAMD_POST=split selects the 4-kernel post-processing
-    int last_segs = 0;
-    unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-segment phase cycle sums
     uint8_t qtable[64];
-    QuantConsts qc;
     int prefix_w = -1, prefix_h = -1, prefix_q = -1;
     // profiling: a ring of event quadruples so callers can time many async encodes and read
     // the per-kernel durations after ONE synchronisation
@@ -65,57 +52,56 @@ struct JpegAmdEncoder {
     uint64_t calls = 0;          // encodes enqueued since profiling was (re)enabled
     int last_slot = -1;
     // last call
+    int last_segs = 0;
     hipStream_t last_stream = nullptr;
     bool pending = false;
     bool timed = false;
 };
 
-static int segs_for(int w, int h, int *bw, int *bh, int *spr, int seg_blocks = kSegBlocks) {
+static int segs_for(int w, int h, int *bw, int *bh, int *spr) {
     const int blocks_w = (w + 7) / 8, blocks_h = (h + 7) / 8;
-    const int per_row = (blocks_w + seg_blocks - 1) / seg_blocks;
+    const int per_row = (blocks_w + kSegBlocks - 1) / kSegBlocks;
     if (bw) *bw = blocks_w;
     if (bh) *bh = blocks_h;
     if (spr) *spr = per_row;
     return blocks_h * per_row;
 }
 
-extern "C" const char *jpegamd_version(void) { return "jpegamd 0.1 (gfx950)"; }
+extern "C" const char *jpegamd_version(void) { return "jpegamd 0.2 (gfx950)"; }
 
-extern "C" int32_t jpegamd_debug_quant_consts(int32_t quality, float *mult, float *bias, float *thr, double *delta,
-                                              uint8_t *table) {
-    uint8_t t[64];
-    QuantConsts qc;
-    double d[64];
-    quant_table_for_quality(quality, t);
-    derive_quant_consts(t, &qc, d);
-    if (mult) std::memcpy(mult, qc.mult, sizeof(qc.mult));
-    if (bias) std::memcpy(bias, qc.bias, sizeof(qc.bias));
-    if (thr) std::memcpy(thr, qc.thr, sizeof(qc.thr));
-    if (delta) std::memcpy(delta, d, sizeof(d));
-    if (table) std::memcpy(table, t, 64);
+extern "C" int32_t jpegamd_segment_meta_words(void) { return kSegMetaWords; }
+
+extern "C" int32_t jpegamd_debug_quant_table(int32_t quality, uint8_t *table) {
+    if (!table) return JPEGAMD_ERR_ARG;
+    quant_table_for_quality(quality, table);
     return JPEGAMD_OK;
 }
 
+// Host-only: the constants of the fast path for `quality` (tests pin them against the oracle's arithmetic).  Reentrant.
 extern "C" int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, float *bias, double *delta) {
     uint8_t t[64];
-    static MfmaTables mt;
+    MfmaTables *mt = new (std::nothrow) MfmaTables;
+    if (!mt) return JPEGAMD_ERR_HIP;
     double d[64];
     quant_table_for_quality(quality, t);
-    derive_mfma_tables(t, &mt, d);
-    if (qmul) std::memcpy(qmul, mt.qmul, sizeof(mt.qmul));
-    if (qthr) std::memcpy(qthr, mt.qthr, sizeof(mt.qthr));
-    if (bias) *bias = mt.bias;
+    derive_mfma_tables(t, mt, d);
+    if (qmul) std::memcpy(qmul, mt->qmul, sizeof(mt->qmul));
+    if (qthr) std::memcpy(qthr, mt->qthr, sizeof(mt->qthr));
+    if (bias) *bias = mt->bias;
     if (delta) std::memcpy(delta, d, sizeof(d));
+    delete mt;
     return JPEGAMD_OK;
 }
 
 extern "C" int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr /*[4 groups][2 lane halves]*/) {
     uint8_t t[64];
-    static MfmaTables mt;
     if (!grp_thr) return JPEGAMD_ERR_ARG;
+    MfmaTables *mt = new (std::nothrow) MfmaTables;
+    if (!mt) return JPEGAMD_ERR_HIP;
     quant_table_for_quality(quality, t);
-    derive_mfma_tables(t, &mt, nullptr, true);
-    std::memcpy(grp_thr, mt.grp_thr, sizeof(mt.grp_thr));
+    derive_mfma_tables(t, mt, nullptr);
+    std::memcpy(grp_thr, mt->grp_thr, sizeof(mt->grp_thr));
+    delete mt;
     return JPEGAMD_OK;
 }
 
@@ -132,29 +118,17 @@ extern "C" uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height) {
     return JPEGAMD_JFIF_PREFIX_BYTES + 2 + 2 * ((nb * kMaxBlockBits + 7) / 8 + 1) + 16;
 }
 
-static void free_scratch(JpegAmdEncoder *e) {
-    hipFree(e->seg_words); hipFree(e->seg_bits); hipFree(e->seg_syms); hipFree(e->seg_exact);
-    hipFree(e->seg_ff); hipFree(e->ovf_words); hipFree(e->seg_bitstart); hipFree(e->seg_ffstart);
-    e->seg_words = e->seg_bits = e->seg_syms = e->seg_exact = e->seg_ff = e->ovf_words = nullptr;
-    e->seg_bitstart = e->seg_ffstart = nullptr;
-}
-
-static int32_t alloc_scratch(JpegAmdEncoder *e, int max_w, int max_h) {
-    const int segs = segs_for(max_w, max_h, nullptr, nullptr, nullptr);
-    const int segs_m = segs_for(max_w, max_h, nullptr, nullptr, nullptr, kSegBlocksM);
-    size_t seg_words = (size_t)segs * kSegCapWords;
-    if ((size_t)segs_m * kSegCapWordsM > seg_words) seg_words = (size_t)segs_m * kSegCapWordsM;
-    HIP_TRY(hipMalloc((void **)&e->seg_words, seg_words * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->ovf_words, (size_t)segs * kOvfWords * 64 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->seg_bits, (size_t)segs * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->seg_syms, (size_t)segs * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->seg_exact, (size_t)segs * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->seg_ff, (size_t)segs * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->seg_bitstart, ((size_t)segs + 1) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&e->seg_ffstart, ((size_t)segs + 1) * sizeof(uint64_t)));
-    e->max_w = max_w; e->max_h = max_h; e->max_segs = segs; e->max_segs_m = segs_m;
-    return JPEGAMD_OK;
-}
+// Allocation failures free everything allocated so far (jpegamd_encoder_destroy tolerates a half-built context).
+#define HIP_TRY_CREATE(expr)                                                                    \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            std::fprintf(stderr, "jpegamd: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                                   \
+            jpegamd_encoder_destroy(e);                                                         \
+            return JPEGAMD_ERR_HIP;                                                             \
+        }                                                                                       \
+    } while (0)
 
 extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_width, int32_t max_height) {
     if (!out || max_width <= 0 || max_height <= 0 || max_width > 65535 || max_height > 65535) return JPEGAMD_ERR_ARG;
@@ -166,36 +140,36 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     }
     JpegAmdEncoder *e = new (std::nothrow) JpegAmdEncoder();
     if (!e) return JPEGAMD_ERR_HIP;
-    HIP_TRY(hipGetDevice(&e->device));
-    int32_t rc = alloc_scratch(e, max_width, max_height);
-    if (rc) { jpegamd_encoder_destroy(e); return rc; }
-    HIP_TRY(hipMalloc((void **)&e->huff, 272 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->prefix, 512));
-    HIP_TRY(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
-    HIP_TRY(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
-    HIP_TRY(hipMalloc((void **)&e->seg_tail, (size_t)e->max_segs + 16));
-    e->max_tiles = ((max_height + 7) / 8) * (((max_width + 7) / 8 + kTileBlocks - 1) / kTileBlocks);
-    HIP_TRY(hipMalloc((void **)&e->tile_items, (size_t)e->max_tiles * kTileItemCap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->tile_ctr, 64 * 128));          // kTileGroups cache lines
-    HIP_TRY(hipMemset(e->tile_ctr, 0, 64 * 128));
-    HIP_TRY(hipMalloc((void **)&e->chunk_ff, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void **)&e->chunk_b0, ((size_t)finalize_chunks(e->max_segs) + 1) * sizeof(unsigned long long)));
-    if (const char *post = std::getenv("JPEGAMD_POST")) e->use_finalize = std::strcmp(post, "split") != 0;
-    if (std::getenv("JPEGAMD_STAMPS")) {
-        HIP_TRY(hipMalloc((void **)&e->stamps_dev, (size_t)e->max_segs * 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(e->stamps_dev, 0, (size_t)e->max_segs * 16 * sizeof(unsigned long long)));
-    }
     std::memset(&e->mirror, 0, sizeof(e->mirror));
-    // Kernel selection is fixed per context (development / A-B switches; defaults are the fast paths).
-    if (const char *force = std::getenv("JPEGAMD_KERNEL")) {
-        e->force_generic = std::strcmp(force, "generic") == 0;
-        e->use_mfma = !(e->force_generic || std::strcmp(force, "aan") == 0);
-        e->split_pipeline = std::strcmp(force, "mfma-fused") != 0;
+    e->tables_host = new (std::nothrow) MfmaTables;
+    if (!e->tables_host) { delete e; return JPEGAMD_ERR_HIP; }
+    HIP_TRY_CREATE(hipGetDevice(&e->device));
+    e->max_w = max_width; e->max_h = max_height;
+    e->max_segs = segs_for(max_width, max_height, nullptr, nullptr, nullptr);
+    e->max_tiles = ((max_height + 7) / 8) * (((max_width + 7) / 8 + kTileBlocks - 1) / kTileBlocks);
+    const size_t segs = (size_t)e->max_segs + 16;                 // k_finalize reads the per-segment arrays four at a time
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.words, (size_t)e->max_segs * kSegCapWords * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.bits, segs * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.syms, segs * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.exact, segs * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.edge, segs * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.ffin, segs * 8 * sizeof(uint16_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->huff, 272 * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->prefix, 512));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
+    HIP_TRY_CREATE(hipMemset(e->stats_dev, 0, sizeof(ScanStats)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_items, (size_t)e->max_tiles * kTileItemCap * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_ctr, 64 * 128));          // ticket-group cache lines
+    HIP_TRY_CREATE(hipMemset(e->tile_ctr, 0, 64 * 128));
+    if (std::getenv("JPEGAMD_STAMPS")) {
+        const size_t n = (size_t)(e->max_segs > 4096 ? e->max_segs : 4096) * 16 * sizeof(unsigned long long);
+        HIP_TRY_CREATE(hipMalloc((void **)&e->stamps_dev, n));
+        HIP_TRY_CREATE(hipMemset(e->stamps_dev, 0, n));
     }
-    if (const char *ent = std::getenv("JPEGAMD_ENTROPY")) e->entropy_backend = std::strcmp(ent, "lane") == 0 ? 0 : 1;
     uint32_t words[272];
     build_huffman_words(words);
-    HIP_TRY(hipMemcpy(e->huff, words, sizeof(words), hipMemcpyHostToDevice));
+    HIP_TRY_CREATE(hipMemcpy(e->huff, words, sizeof(words), hipMemcpyHostToDevice));
     *out = e;
     return JPEGAMD_OK;
 }
@@ -203,10 +177,11 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
 extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (!e) return JPEGAMD_OK;
     if (e->pending) hipStreamSynchronize(e->last_stream);
-    free_scratch(e);
-    hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev); hipFree(e->chunk_ff); hipFree(e->chunk_b0); hipFree(e->seg_tail);
-    hipFree(e->tile_items); hipFree(e->tile_ctr);
+    hipFree(e->seg.words); hipFree(e->seg.bits); hipFree(e->seg.syms); hipFree(e->seg.exact); hipFree(e->seg.edge); hipFree(e->seg.ffin);
+    hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev);
+    hipFree(e->tile_items); hipFree(e->tile_ctr); hipFree(e->stamps_dev);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
+    delete e->tables_host;
     delete e;
     return JPEGAMD_OK;
 }
@@ -244,14 +219,9 @@ static int32_t prepare_constants(JpegAmdEncoder *e, const JpegAmdImage *img, boo
     const int q = (img->quality <= 0) ? 50 : (img->quality > 100 ? 100 : img->quality);
     if (q != e->cur_quality) {
         quant_table_for_quality(q, e->qtable);
-        derive_quant_consts(e->qtable, &e->qc, nullptr);
-        e->std_kernel = std_consts_match_baked(e->qtable) && !e->force_generic;
-        if (e->use_mfma) {
-            static MfmaTables host_tables;                       // 25 KiB: keep it off the stack
-            derive_mfma_tables(e->qtable, &host_tables, nullptr, e->split_pipeline);
-            if (e->pending) HIP_TRY(hipStreamSynchronize(e->last_stream));
-            HIP_TRY(hipMemcpy(e->tables_dev, &host_tables, sizeof(MfmaTables), hipMemcpyHostToDevice));
-        }
+        derive_mfma_tables(e->qtable, e->tables_host, nullptr);
+        if (e->pending) HIP_TRY(hipStreamSynchronize(e->last_stream));
+        HIP_TRY(hipMemcpy(e->tables_dev, e->tables_host, sizeof(MfmaTables), hipMemcpyHostToDevice));
         e->cur_quality = q;
     }
     if (need_prefix && (e->prefix_w != img->width || e->prefix_h != img->height || e->prefix_q != q)) {
@@ -265,14 +235,12 @@ static int32_t prepare_constants(JpegAmdEncoder *e, const JpegAmdImage *img, boo
 }
 
 // Does a w x h image fit the scratch of `e`?  Every derived count is checked on its own: an image wider than max_w with
-// fewer rows can need MORE 256-block segments or 32-block tiles than max_w x max_h although it has fewer 64-block
-// segments (per-row rounding) -- sizing by one of the counts alone let k_entropy write past seg_words.
+// fewer rows can need MORE segments or tiles than max_w x max_h (per-row rounding).
 static bool context_fits(const JpegAmdEncoder *e, int w, int h) {
     if (!e || w <= 0 || h <= 0) return false;
     const int bw = (w + 7) / 8, bh = (h + 7) / 8;
     const int tiles = bh * ((bw + kTileBlocks - 1) / kTileBlocks);
-    return segs_for(w, h, nullptr, nullptr, nullptr) <= e->max_segs &&
-           segs_for(w, h, nullptr, nullptr, nullptr, kSegBlocksM) <= e->max_segs_m && tiles <= e->max_tiles;
+    return segs_for(w, h, nullptr, nullptr, nullptr) <= e->max_segs && tiles <= e->max_tiles;
 }
 
 static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageDesc *d) {
@@ -286,8 +254,7 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     // Y = (77 R + 150 G + 29 B) >> 8 (natural_c/src/core/converter.c:51); weights follow the STORED byte order.
     d->weights = img->channel_order == JPEGAMD_ORDER_BGR ? (29u | (150u << 8) | (77u << 16))
                                                          : (77u | (150u << 8) | (29u << 16));
-    d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row,
-                           (e && e->use_mfma) ? kSegBlocksM : kSegBlocks);
+    d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row);
     d->tiles_per_row = (d->blocks_w + kTileBlocks - 1) / kTileBlocks;
     d->num_tiles = d->tiles_per_row * d->blocks_h;
     d->tile_begin = 0; d->tile_end = d->num_tiles;
@@ -297,71 +264,34 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     return JPEGAMD_OK;
 }
 
-static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
-                                void *stream, hipEvent_t mid = nullptr);
-
-static TransformOut transform_out(const JpegAmdEncoder *e) {
-    TransformOut t;
-    std::memset(&t, 0, sizeof(t));
-    t.seg_words = e->seg_words; t.seg_bits = e->seg_bits; t.seg_syms = e->seg_syms; t.seg_exact = e->seg_exact;
-    t.ovf_words = e->ovf_words; t.huff = e->huff;
-    return t;
-}
-
-static FinReset fin_reset(const JpegAmdEncoder *e, int num_segs) {
-    FinReset r;
-    (void)num_segs;
-    r.stats = e->stats_dev;
-    return r;
-}
-
-static int launch_any_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
-                                void *stream, hipEvent_t mid) {
-    // `mid` (optional) is recorded after the transform proper, before the symbol kernel of the split pipeline
-    if (e->use_mfma) {
-        TransformOutM to;
-        std::memset(&to, 0, sizeof(to));
-        to.seg_words = e->seg_words; to.seg_bits = e->seg_bits; to.seg_syms = e->seg_syms; to.seg_exact = e->seg_exact;
-        to.huff = e->huff; to.tables = e->tables_dev; to.stamps = e->stamps_dev; to.seg_tail = e->seg_tail;
-        to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
-        to.reset = fin_reset(e, im.num_segs);
-        if (!e->split_pipeline) {
-            const int err = launch_transform_mfma(im, to, taps, stream);
-            if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
-            return err;
-        }
-        to.tile_items = e->tile_items; to.tile_ctr = e->tile_ctr;
-        if (int err = launch_tile_transform(im, to, taps, stream)) return err;
-        if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
-        EntropyArgs ea;
-        std::memset(&ea, 0, sizeof(ea));
-        ea.tile_items = e->tile_items;
-        ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
-        ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
-        ea.seg_words = e->seg_words; ea.seg_bits = e->seg_bits; ea.seg_syms = e->seg_syms; ea.seg_exact = e->seg_exact;
-        ea.seg_tail = e->seg_tail;
-        return launch_entropy(ea, stream);
-    }
-    TransformOut to = transform_out(e);
+// k_tile_transform, then k_entropy; `mid` (optional) is recorded between the two.
+static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
+                                        void *stream, hipEvent_t mid = nullptr) {
+    TransformOutM to;
+    std::memset(&to, 0, sizeof(to));
+    to.tables = e->tables_dev; to.stamps = e->stamps_dev;
     to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
-    to.reset = fin_reset(e, im.num_segs);
-    const int aan_err = launch_transform(im, e->qc, to, taps, e->std_kernel, e->entropy_backend, stream);
+    to.tile_items = e->tile_items; to.tile_ctr = e->tile_ctr;
+    if (int err = launch_tile_transform(im, to, taps, stream)) return err;
     if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
-    return aan_err;
+    EntropyArgs ea;
+    std::memset(&ea, 0, sizeof(ea));
+    ea.tile_items = e->tile_items;
+    ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
+    ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
+    ea.seg = e->seg;
+    return launch_entropy(ea, stream);
 }
 
 static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, uint64_t out_capacity, uint64_t *out_size_dev,
                         int32_t with_container, hipStream_t stream) {
     FinalizeArgs fa;
     std::memset(&fa, 0, sizeof(fa));
-    fa.seg_words = e->seg_words; fa.seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
-    fa.seg_bits = e->seg_bits;
-    fa.seg_tail = e->use_mfma ? e->seg_tail : nullptr;
+    fa.seg = e->seg;
     fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
     fa.out = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size = out_size_dev; fa.stats = e->stats_dev;
     fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
     fa.write_eoi = with_container ? 1 : 0;
-    fa.seg_ff = e->seg_ff; fa.chunk_ff = e->chunk_ff; fa.chunk_b0 = e->chunk_b0;
     return launch_finalize(fa, stream);
 }
 
@@ -373,7 +303,7 @@ static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, u
 // 0xFF stuffing and the zero-padded flush depend on the global byte phase and so happen once, at the root.
 // ---------------------------------------------------------------------------------------------------------
 static int32_t shard_desc(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t by0, int32_t by1, ImageDesc *im) {
-    if (!e || !e->use_mfma || !e->split_pipeline || !e->use_finalize) return JPEGAMD_ERR_ARG;   // split pipeline only
+    if (!e) return JPEGAMD_ERR_ARG;
     int32_t rc = describe(e, img, im);
     if (rc) return rc;
     if (by0 < 0 || by1 < by0 || by1 > im->blocks_h) return JPEGAMD_ERR_ARG;
@@ -394,7 +324,7 @@ extern "C" int32_t jpegamd_encode_rows_async(JpegAmdEncoder *e, const JpegAmdIma
     im.seg_begin = block_row_begin * im.segs_per_row;
     im.seg_end = block_row_end * im.segs_per_row;
     hipStream_t stream = (hipStream_t)stream_;
-    if (launch_any_transform(e, im, false, nullptr, nullptr, nullptr, stream, nullptr)) return JPEGAMD_ERR_HIP;
+    if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, nullptr)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
     e->last_stream = stream;
     e->pending = true;
@@ -409,8 +339,7 @@ static int32_t exchange_args(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t
     if (rc) return rc;
     if (!dense || !meta) return JPEGAMD_ERR_ARG;
     std::memset(x, 0, sizeof(*x));
-    x->seg_words = e->seg_words; x->seg_stride = (uint32_t)kSegCapWordsM;
-    x->seg_bits = e->seg_bits; x->seg_syms = e->seg_syms; x->seg_exact = e->seg_exact; x->seg_tail = e->seg_tail;
+    x->seg = e->seg;
     x->s0 = by0 * im.segs_per_row; x->s1 = by1 * im.segs_per_row;
     x->dense = dense; x->dense_cap_words = cap; x->meta = meta; x->total_words = total;
     x->status = &e->stats_dev->status;
@@ -449,8 +378,6 @@ extern "C" int32_t jpegamd_finalize_async(JpegAmdEncoder *e, const JpegAmdImage 
     rc = prepare_constants(e, img, with_container != 0);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    // the status word is normally cleared by the transform kernel of the same call
-    HIP_TRY(hipMemsetAsync(&e->stats_dev->status, 0, sizeof(uint32_t), stream));
     if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
     e->last_stream = stream;
@@ -478,44 +405,30 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         ++e->calls;
         HIP_TRY(hipEventRecord(ev[0], stream));
     }
-    if (launch_any_transform(e, im, false, nullptr, nullptr, nullptr, stream, timed ? ev[1] : nullptr)) return JPEGAMD_ERR_HIP;
-    const uint32_t seg_stride = e->use_mfma ? (uint32_t)kSegCapWordsM : (uint32_t)kSegCapWords;
-    if (e->use_finalize) {
-        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
-        if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
-    } else {
-        if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
-        if (launch_scan_bits(e->seg_bits, e->seg_syms, e->seg_exact, e->seg_bitstart, im.num_segs, e->stats_dev, stream))
-            return JPEGAMD_ERR_HIP;
-        PackArgs pa;
-        std::memset(&pa, 0, sizeof(pa));
-        pa.seg_stride = seg_stride;
-        pa.seg_words = e->seg_words; pa.seg_bits = e->seg_bits; pa.seg_bitstart = e->seg_bitstart;
-        pa.seg_ff = e->seg_ff; pa.seg_ffstart = e->seg_ffstart; pa.num_segs = im.num_segs;
-        pa.out = (uint8_t *)out_dev; pa.out_capacity = out_capacity; pa.out_size = out_size_dev; pa.stats = e->stats_dev;
-        pa.prefix = e->prefix; pa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
-        pa.write_eoi = with_container ? 1 : 0;
-        if (launch_count_ff(pa, stream)) return JPEGAMD_ERR_HIP;
-        if (launch_scan_ff(e->seg_ff, e->seg_ffstart, im.num_segs, e->stats_dev, stream)) return JPEGAMD_ERR_HIP;
-        if (launch_pack(pa, stream)) return JPEGAMD_ERR_HIP;
-    }
+    if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, timed ? ev[1] : nullptr)) return JPEGAMD_ERR_HIP;
+    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
+    if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
     if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
     e->last_segs = im.num_segs;
-
     e->last_stream = stream;
     e->pending = true;
     e->timed = timed;
     return JPEGAMD_OK;
 }
 
+// The capacity status is STICKY on the device: every kernel only ORs into it, and it is cleared here, after it was read.
+// A pipelined caller that keeps several encodes in flight on one context therefore learns about an overflow in ANY of
+// them (JPEGAMD_ERR_HUFF_CAPACITY, jpeg_compression.c:205-206) at its next finish; which one it was follows from the sizes
+// (*out_size_dev holds the would-be size of each call even when it did not fit).
 extern "C" int32_t jpegamd_encoder_finish(JpegAmdEncoder *e, JpegAmdStats *stats) {
     if (!e) return JPEGAMD_ERR_ARG;
     if (!e->pending) return JPEGAMD_ERR_ARG;
-    if (stats && e->use_finalize)       // symbol / exact-path totals are only summed when somebody asks
-        if (launch_sum_stats(e->seg_syms, e->seg_exact, e->last_segs, e->stats_dev, e->last_stream)) return JPEGAMD_ERR_HIP;
+    if (stats)                          // symbol / exact-path totals are only summed when somebody asks
+        if (launch_sum_stats(e->seg.syms, e->seg.exact, e->last_segs, e->stats_dev, e->last_stream)) return JPEGAMD_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(e->last_stream));
     e->pending = false;
     HIP_TRY(hipMemcpy(&e->mirror, e->stats_dev, sizeof(ScanStats), hipMemcpyDeviceToHost));
+    if (e->mirror.status) HIP_TRY(hipMemset(&e->stats_dev->status, 0, sizeof(uint32_t)));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         stats->jfif_bytes = e->mirror.out_size;
@@ -541,17 +454,17 @@ extern "C" int32_t jpegamd_debug_stages(JpegAmdEncoder *e, const JpegAmdImage *i
     if (rc) return rc;
     rc = prepare_constants(e, img, false);
     if (rc) return rc;
-    if (launch_any_transform(e, im, true, y_centered, quant_zigzag, exact_mask, nullptr)) return JPEGAMD_ERR_HIP;
+    if (launch_transform_and_entropy(e, im, true, y_centered, quant_zigzag, exact_mask, nullptr)) return JPEGAMD_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(nullptr));
     return JPEGAMD_OK;
 }
 
-// Diagnostic: copy the per-segment phase cycle sums of the last launch (null unless JPEGAMD_STAMPS is set
+// Diagnostic: copy the per-wave phase cycle sums of the last launch (null unless JPEGAMD_STAMPS is set
 // in the environment AND the library was built with -DJPEGAMD_STAMPS).  Not part of the public header.
-extern "C" int32_t jpegamd_debug_read_stamps(JpegAmdEncoder *e, unsigned long long *host, int64_t nsegs) {
-    if (!e || !e->stamps_dev || !host || nsegs > e->max_segs) return JPEGAMD_ERR_ARG;
+extern "C" int32_t jpegamd_debug_read_stamps(JpegAmdEncoder *e, unsigned long long *host, int64_t nwaves) {
+    if (!e || !e->stamps_dev || !host || nwaves > (e->max_segs > 4096 ? e->max_segs : 4096)) return JPEGAMD_ERR_ARG;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(host, e->stamps_dev, (size_t)nsegs * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(host, e->stamps_dev, (size_t)nwaves * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return JPEGAMD_OK;
 }
 
@@ -631,7 +544,7 @@ int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64
     HIP_TRY(hipMalloc((void **)&y_dev, 64));
     HIP_TRY(hipMalloc((void **)&zz_dev, 128));
     HIP_TRY(hipMalloc((void **)&dct_dev, 256));
-    int err = launch_any_transform(e, im, true, y_dev, zz_dev, nullptr, nullptr);
+    int err = launch_transform_and_entropy(e, im, true, y_dev, zz_dev, nullptr, nullptr);
     if (!err) err = launch_dct_exact(y_dev, dct_dev, 1, nullptr);
     if (!err) err = (int)hipMemcpy(y, y_dev, 64, hipMemcpyDeviceToHost);
     if (!err) err = (int)hipMemcpy(zz, zz_dev, 128, hipMemcpyDeviceToHost);

@@ -35,8 +35,6 @@ constexpr int kAfrBatch = JPEGAMD_AFR_BATCH;   // k-steps whose A fragments (2 x
 #define JPEGAMD_TILE_MAX_WGS 512
 #endif
 constexpr int kWavesT = JPEGAMD_TILE_WG_WAVES;  // waves per workgroup; they share the 24 KiB matrix image in LDS
-constexpr uint32_t kItDc = 0x80000000u;         // item is a DC difference
-constexpr uint32_t kItFirst = 0x40000000u;      // ... of the first block of its tile: value is the absolute DC
 
 struct RawRow { uint32_t d[6]; };      // one block row: 8 pixels x 3 bytes
 
@@ -92,13 +90,16 @@ __device__ __forceinline__ bf16x8 luma_row8_bf16(const RawRow &raw, uint32_t w) 
 #define TSTAMP(i) do { } while (0)
 #endif
 
-constexpr int kTileGroups = 64;                 // ticket counters (one cache line each) of the dynamic tile hand-out
-// 0: rows are requested at the top of their own tile and the other waves of the SIMD cover the latency;
-// 1: the next tile's pixel rows are requested right after the luma step (24 live VGPRs across the whole body: spills);
-// 2: ... requested after the exact-order step, in flight during the counts and appends.
-#ifndef JPEGAMD_TILE_PREFETCH
-#define JPEGAMD_TILE_PREFETCH 0
+#ifndef JPEGAMD_TILE_SPREAD
+#define JPEGAMD_TILE_SPREAD 0
 #endif
+#ifndef JPEGAMD_TILE_GROUPS
+#define JPEGAMD_TILE_GROUPS 64
+#endif
+#ifndef JPEGAMD_ITEM_AUX
+#define JPEGAMD_ITEM_AUX 0           // cache policy bits of the item stores (0 default, 2 nt, 16 sc1)
+#endif
+constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket counters (one cache line each) of the dynamic tile hand-out
 #ifndef JPEGAMD_TILE_WAVES
 #define JPEGAMD_TILE_WAVES 4
 #endif
@@ -142,7 +143,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
             s_cos[t] = kCosFM[t];
             if (t < 8) s_grp[t] = out.tables->grp_thr[t];
         }
-        if (blockIdx.x == 0 && t == 0 && out.reset.stats) out.reset.stats->status = 0u;   // cleared for this call's finalize kernels
     }
     __syncthreads();
 
@@ -163,7 +163,17 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     // range of tiles and hands them to its waves through its OWN ticket counter (own cache line).  The ticket for
     // the tile after next is requested one iteration ahead, so its latency is hidden like the pixel rows'.
     const int groups = 1 << sch.grp_shift;
-    const int grp = (int)blockIdx.x & (groups - 1);
+#if JPEGAMD_TILE_SPREAD
+    // Members of a ticket group on DIFFERENT XCDs (consecutive workgroups; blocks are dealt round-robin over the XCDs):
+    // the XCDs hold different clocks under this load (1.87 .. 2.06 GHz measured), a group confined to one of them
+    // finishes up to 10 % early or late.  Needs a grid that is a multiple of the group count (else: identity).
+    const int members = (int)gridDim.x >> sch.grp_shift;
+    const int bid = (members << sch.grp_shift) == (int)gridDim.x ? ((int)blockIdx.x % members) * groups + (int)blockIdx.x / members
+                                                                  : (int)blockIdx.x;
+#else
+    const int bid = (int)blockIdx.x;
+#endif
+    const int grp = bid & (groups - 1);
     const int grp_waves = ((((int)gridDim.x - 1 - grp) >> sch.grp_shift) + 1) * kWavesT;   // waves of this group
 #if JPEGAMD_TILE_INTERLEAVE
     // A group owns the CHUNKS (kWavesT consecutive tiles, what its 8 waves work on side by side) c = grp, grp + groups, ...
@@ -183,7 +193,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     const auto to_tile = [&](int li) { return li; };
 #endif
     uint32_t *ctr = out.tile_ctr + grp * 32;                                                // [0] tickets, [1] waves done
-    const int first = grp_lo + ((int)blockIdx.x >> sch.grp_shift) * kWavesT + wave;
+    const int first = grp_lo + (bid >> sch.grp_shift) * kWavesT + wave;
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
     struct TileGeo { int by, tbx0, nblk, bx; bool interior; };
     const auto geo = [&](int tile) {
@@ -214,10 +224,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     };
     RawRow raw[4];
     TileGeo tg = geo(first < grp_hi ? to_tile(first) : im.tile_begin);
-#if JPEGAMD_TILE_PREFETCH
-    if (first < grp_hi && tg.interior) request_rows(tg, raw);
-#endif
-    int nxt = first < grp_hi ? grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket()) : grp_hi;
 #ifdef JPEGAMD_STAMPS
     unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_last)::"memory");
@@ -227,7 +233,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll 1
     for (int li = first; li < grp_hi;) {
         const int tile = to_tile(li);
-        const uint32_t ticket_v = ticket();                   // consumed at the bottom of the iteration
         const int by = tg.by, nblk = tg.nblk, bx = tg.bx;
         const int py0 = by * 8, px0 = bx * 8;
         const bool active = b < nblk, interior = tg.interior;
@@ -236,9 +241,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         bf16x8 bfrag[4];
         if (interior) {
-#if !JPEGAMD_TILE_PREFETCH
             request_rows(tg, raw);
-#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_bf16(raw[s], im.weights);
         } else {
@@ -250,12 +253,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     bfrag[s][j] = (__bf16)(float)(luma_clamped(im, px0 + j, py0 + 2 * s + h) - 128);
         }
         TSTAMP(1);   // wait for the prefetched rows + luma
-        TileGeo tg_next = tg;                                 // one division per tile: the geometry is carried over
-#if JPEGAMD_TILE_PREFETCH == 1
-        if (nxt < grp_hi) { tg_next = geo(to_tile(nxt)); if (tg_next.interior) request_rows(tg_next, raw); }
-#else
-        if (nxt < grp_hi) tg_next = geo(to_tile(nxt));
-#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x8 *>(&s_pix[wave][(2 * s + h) * 132 + b * 4]) = bfrag[s];
         TSTAMP(2);   // issue of the next tile's loads
@@ -348,6 +345,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         if (!active) flagbits = 0u;
         TSTAMP(4);   // quantise
 
+        // The ticket for this wave's NEXT tile is requested here and collected before the appends (its latency hides
+        // behind the exact-order and count phases).  Round 1 asked one whole iteration earlier, for the tile after next:
+        // every wave then sat on a reserved, unstarted tile when its group ran dry, and the last waves of a group
+        // finished two tile-times (11 us of 58) after the first (profiles/r02_stamps_interleaved.txt).
+        const uint32_t ticket_v = ticket();
         // ---- 4. exact-order recomputation of flagged coefficients ------------------------------
         uint64_t exact_mask = 0;
         unsigned long long fm = __ballot(flagbits != 0u);
@@ -389,11 +391,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
         TSTAMP(5);   // exact fallback
 
-#if JPEGAMD_TILE_PREFETCH == 2
-        // The next tile's rows are requested HERE: their 24 registers are live only across the counts and appends
-        // (and the loop head), not across the MFMA and quantiser phases where the register file is full.
-        if (nxt < grp_hi && tg_next.interior) request_rows(tg_next, raw);
-#endif
         // ---- 5. symbol counts per (lane, group), packed one byte per group -> list positions ---------
         // A block's list is ordered by zigzag position: group 0 of lane h=0, group 0 of lane h=1, group 1 of h=0, ...
         const bool eob = (h == 1) && (gact[3] ? (n[31] == 0) : true);             // rle.c:121-123 (zigzag 63)
@@ -428,12 +425,18 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // The ticket requested at the top of the iteration is collected here, BEFORE the item stores are issued:
         // the wait for it then covers no younger memory operation (built with the atomic optimizer off -- its
         // expansion reads the result back, and waits for vmcnt(0), right behind the atomic).
-        const int nxt_ticket = grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
-        // ---- 6. append the items: slot 0 of the list is a zero sentinel ("previous item" of the first) ----
+        const int nxt = grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
+        TileGeo tg_next = tg;
+        if (nxt < grp_hi) tg_next = geo(to_tile(nxt));
+        // ---- 6. append the items (from word 0 of the tile's list) ----
         // Per stored item: one SDWA add writes the zigzag position into the upper half of the value's own register,
         // one buffer store (32-bit offset against the tile's descriptor), one offset increment.
         uint32_t *list = out.tile_items + (size_t)tile * kTileItemCap;
-        const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list + 1, 0, (kTileItemCap - 1) * 4, 0x00020000);
+        #ifdef JPEGAMD_NO_ITEM_STORE           // timing-only build: zero records, the range check drops every item store (stream, waits unchanged)
+        const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, 0, 0x00020000);
+#else
+        const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, kTileRecord * 4, 0x00020000);
+#endif
         if (active) {
             uint32_t off = 0;
 #pragma unroll
@@ -441,7 +444,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 if (!gact[G]) continue;
                 off = (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
                 const uint32_t zg = (uint32_t)(16 * G + 8 * h);
-                if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, 0); off += 4u; }
+                if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, JPEGAMD_ITEM_AUX); off += 4u; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
@@ -449,18 +452,18 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                         uint32_t item = (uint32_t)v;
                         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
                             : "+v"(item) : "v"(zg), "n"(j));
-                        __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
                         off += 4u;
                     }
                 }
             }
             if (eob) {
                 if (!gact[3]) off = (blk_base + (starts >> 24)) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b32(64u << 16, lrsrc, off, 0, 0);     // value 0, not DC = EOB
+                __builtin_amdgcn_raw_buffer_store_b32(64u << 16, lrsrc, off, 0, JPEGAMD_ITEM_AUX);     // value 0, not DC = EOB
             }
         }
         if (lane == 0) {
-            list[0] = 0u;
+            if (t_all & 1u) list[t_all] = kItNop;                   // k_entropy's lanes take two items each: even count per list
             *reinterpret_cast<uint4 *>(list + kTileRecord) =
                 make_uint4(t_all, (uint32_t)__builtin_amdgcn_readlane(n[0], nblk - 1), (uint32_t)nexact, 0u);
         }
@@ -468,7 +471,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         TSTAMP(7);   // appends
         li = nxt;
         tg = tg_next;
-        nxt = nxt_ticket;
     }
     // the last wave of the group re-arms its counters for the next launch on this context
     if (lane == 0 && atomicAdd(ctr + 1, 1u) == (uint32_t)grp_waves - 1u) {
@@ -504,161 +506,6 @@ int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool ta
     const dim3 grid(wgs), block(64 * kWavesT);
     if (taps) hipLaunchKernelGGL(k_tile_transform<true>, grid, block, 0, (hipStream_t)stream, im, out, sch);
     else hipLaunchKernelGGL(k_tile_transform<false>, grid, block, 0, (hipStream_t)stream, im, out, sch);
-    return (int)hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------
-// k_entropy: one wave per segment, one lane per symbol
-// ------------------------------------------------------------------------------------
-constexpr int kWavesE = 4;
-constexpr int kSegBufWords = 512;               // LDS bit buffer per wave (typical segment: ~90 words); flushed when nearly full
-
-__global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
-    __shared__ uint32_t s_huff[288];                // 272 used; masked garbage items may index a little past it
-    __shared__ uint32_t s_win[kWavesE][kSegBufWords];
-    {
-        const int t = (int)threadIdx.x;
-        s_huff[t] = a.huff[t];
-        if (t < 32) s_huff[256 + t] = t < 16 ? a.huff[256 + t] : 0u;
-    }
-    __syncthreads();
-    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int seg = a.seg_begin + (int)blockIdx.x * kWavesE + wave;
-    if (seg >= a.seg_end) return;
-    uint32_t *win = s_win[wave];
-
-    const int by = seg / a.segs_per_row;
-    const int tx0 = (seg - by * a.segs_per_row) * kSegTiles;
-    const int ntiles = min(kSegTiles, a.tiles_per_row - tx0);
-    const int tile0 = by * a.tiles_per_row + tx0;
-
-    uint32_t *segw = a.seg_words + (size_t)seg * kSegCapWordsM;
-    uint32_t carry_bits = 0, wbase = 0, last_word = 0;
-    int nsym = 0;
-#pragma unroll
-    for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
-    // everything whose address is known up front is requested now: counts and predecessor DCs of the segment's tiles
-    const uint32_t *trec = a.tile_items + (size_t)(tile0 + lane) * kTileItemCap + kTileRecord;      // {items, last DC, exact count, 0}
-    const uint4 rec = lane < ntiles ? *reinterpret_cast<const uint4 *>(trec) : make_uint4(0u, 0u, 0u, 0u);
-    const int tcount = (int)rec.x;
-    const int tprev = (lane < ntiles && tile0 + lane > 0) ? (int)trec[1 - kTileItemCap] : 0;       // the tile before: its last DC
-    uint32_t nexact = rec.z;
-
-    // Flat walk over (tile, batch of 64 items) with the NEXT batch's two loads already in flight.  The walk's state
-    // (tile, offset, count, predecessor DC, symbols of finished tiles) is wave-uniform and lives on the scalar unit.
-    int ti = 0;
-    uint32_t b0 = 0;
-    uint32_t gt = (uint32_t)__builtin_amdgcn_readlane(tcount, 0);
-    int prev_dc_next = __builtin_amdgcn_readlane(tprev, 0);
-    uint32_t nsym_tiles = 0;                                      // uniform part of the symbol count
-    // the segment's lists through one buffer descriptor: scalar offset = tile and batch, lane offset = 4 * lane
-    const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t *>(a.tile_items + (size_t)tile0 * kTileItemCap), 0, ntiles * kTileItemCap * 4, 0x00020000);
-    const int lane4 = lane * 4;
-    uint32_t soff = 0;                                            // byte offset of the current tile's list
-    uint32_t nx_itp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4, 0, 0);       // slot 0 = sentinel ("previous item" of the first)
-    uint32_t nx_it = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4 + 4, 0, 0);
-#pragma unroll 1
-    while (ti < ntiles) {
-        const uint32_t itp = nx_itp, it = nx_it;
-        const uint32_t cur_gt = gt, cur_b0 = b0;
-        const int prev_dc = prev_dc_next;
-        // advance and request
-        b0 += 64;
-        if (b0 >= gt) {
-            nsym_tiles += gt;
-            ++ti;
-            b0 = 0;
-            if (ti < ntiles) {
-                gt = (uint32_t)__builtin_amdgcn_readlane(tcount, ti);
-                prev_dc_next = __builtin_amdgcn_readlane(tprev, ti);
-                soff += (uint32_t)kTileItemCap * 4u;
-            }
-        }
-        // unconditional: after the last batch this re-reads the head of the last tile's list (inside the descriptor, unused)
-        nx_itp = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4, (int)(soff + b0 * 4u), 0);
-        nx_it = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(irsrc, lane4 + 4, (int)(soff + b0 * 4u), 0);
-        {
-            const uint32_t idx = cur_b0 + (uint32_t)lane;
-            const bool valid = idx < cur_gt;
-            // lanes past the end of the list code "nothing": value 0 and a table slot that holds a zero-length code
-            const uint32_t itv = valid ? it : 0u;
-            int v = (int)(short)(itv & 0xFFFFu);
-            const bool isdc = (itv & kItDc) != 0u;
-            if (itv & kItFirst) v -= prev_dc;                // first block of a tile: DC difference against the previous tile
-            const int run = (v && !isdc) ? (int)((itv >> 16) & 0x7Fu) - (int)((itp >> 16) & 0x7Fu) - 1 : 0;   // EOB: symbol 0x00
-            const int nb = 32 - __clz(abs(v));                                                     // rle.c:9-22 (clz(0) = 32)
-            const uint32_t amp = __builtin_amdgcn_ubfe((uint32_t)(v + (v >> 31)), 0u, (uint32_t)nb);   // rle.c:24-35
-            const uint32_t sym = isdc ? (uint32_t)(256 + nb) : (uint32_t)(((run & 15) << 4) | nb);
-            const uint32_t hc = s_huff[valid ? sym : 272u];
-            uint32_t hi = ((hc & 0xFFFFu) << nb) | amp;
-            uint32_t lo = 0;
-            int len = (int)(hc >> 16) + nb;
-            const int zrl = isdc ? 0 : (run >> 4);                                                 // rle.c:99-103
-            hi <<= (32 - len) & 31;                          // len == 0 only with code 0 and no amplitude bits: hi is 0 already
-            const bool any_zrl = __any(zrl != 0);
-            if (__builtin_expect(any_zrl, 0)) {
-                const uint32_t zw = s_huff[0xF0];
-                const uint32_t zc = zw & 0xFFFFu;
-                const int zl = (int)(zw >> 16);
-                unsigned long long a64 = ((unsigned long long)hi << 32);
-                int tot = len;
-                for (int q = 0; q < 3; ++q)
-                    if (q < zrl) { a64 = (a64 >> zl) | ((unsigned long long)zc << (64 - zl)); tot += zl; }
-                hi = (uint32_t)(a64 >> 32);
-                lo = (uint32_t)a64;
-                len = tot;
-                nsym += zrl;
-            }
-            const uint32_t incl_b = wave_incl_scan_u32((uint32_t)len);
-            const uint32_t batch_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl_b, 63);
-            // The loop body holds NO global store: waiting for the next batch's loads (vmcnt) would otherwise
-            // also wait for every younger store to be acknowledged.  Stores happen only in the rare flush.
-            if (__builtin_expect((carry_bits >> 5) - wbase + 124u > (uint32_t)kSegBufWords, 0)) {
-                const uint32_t done = (carry_bits >> 5) - wbase;            // complete words in the buffer
-                uint32_t part = win[done];
-                for (uint32_t j = (uint32_t)lane; j < done; j += 64) segw[wbase + j] = win[j];
-                last_word = win[done - 1];
-#pragma unroll
-                for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
-                if (lane == 0) win[0] = part;
-                wbase += done;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // leave no store pending behind the branch
-            }
-            const uint32_t rel = carry_bits + incl_b - (uint32_t)len - wbase * 32u;
-            {   // empty symbols OR zeros into an in-range word: no divergence
-                const uint32_t w = rel >> 5, sh = rel & 31u;
-                atomicOr(&win[w], __builtin_amdgcn_alignbit(0u, hi, sh));
-                atomicOr(&win[w + 1], __builtin_amdgcn_alignbit(hi, lo, sh));
-                if (__builtin_expect(any_zrl, 0)) atomicOr(&win[w + 2], __builtin_amdgcn_alignbit(lo, 0u, sh));
-            }
-            carry_bits += batch_bits;
-        }
-    }
-    {   // final flush: complete words, then the zero-padded partial word
-        const uint32_t done = (carry_bits >> 5) - wbase;
-        for (uint32_t j = (uint32_t)lane; j < done; j += 64) segw[wbase + j] = win[j];
-        if (done) last_word = win[done - 1];
-        const uint32_t part = win[done];
-        wbase += done;
-        if ((carry_bits & 31u) && lane == 0) segw[wbase] = part;
-        if (lane == 0) win[0] = part;
-    }
-    const int seg_syms = wave_sum_i32(nsym) + (int)nsym_tiles;
-    const int seg_exact = wave_sum_i32((int)nexact);
-    if (lane == 0) {
-        const uint32_t p = carry_bits & 31u, w0 = win[0];
-        const uint32_t tail = p ? ((last_word << p) | (w0 >> (32u - p))) : last_word;
-        a.seg_tail[seg] = (uint8_t)(tail & 0x7Fu);           // what the next segment's first output byte may start with
-        a.seg_bits[seg] = carry_bits;
-        a.seg_syms[seg] = (uint32_t)seg_syms;
-        a.seg_exact[seg] = (uint32_t)seg_exact;
-    }
-}
-
-int launch_entropy(const EntropyArgs &a, void *stream) {
-    if (a.seg_end <= a.seg_begin) return 0;
-    hipLaunchKernelGGL(k_entropy, dim3((a.seg_end - a.seg_begin + kWavesE - 1) / kWavesE), dim3(64 * kWavesE), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

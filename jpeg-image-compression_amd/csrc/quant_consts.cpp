@@ -1,21 +1,19 @@
-// quant_consts.cpp -- host-side derivation of the kernel's per-coefficient constants.
+// quant_consts.cpp -- host-side derivation of the kernels' constants: quantisation table for a quality, the LUT-product
+// matrix as MFMA A fragments, the guard band of the fast quantiser, Huffman code words, the JFIF prefix.
 //
-// For each coefficient k = u*8+v the fused kernel evaluates  zc = aan_k * M_k + (delta_k + 0.5)
-// and trusts floor(zc) as the reference's  roundf(F[u][v] / q)  only when fract(zc) > 2*delta_k.
-// delta_k must bound |z_fast - r_ref| rigorously, where r_ref is the float32 value the
-// reference divides-and-rounds (natural_c/src/core/dct.c:63-96, quantization.c:34-36):
+// Guard band.  The fast path evaluates z = S * (K/q) where S is the LUT sum of a coefficient (matrix pipe) and trusts its
+// rounding as the reference's  roundf(F[u][v] / q)  (natural_c/src/core/dct.c:63-96, quantization.c:34-36) only when z is
+// further than delta from a rounding tie.  delta bounds |z_fast - r_ref| rigorously:
 //
-//   delta_k = (K_k/q_k) * (E_ref_k + E_lut_k)  +  (K_k/(q_k*G_k)) * E_aan_k  +  4u*(zmax_k + 1)
+//   delta = (K/q) * (E_ref + E_mfma + E_split) + 4u (zmax + 1)
 //
-//   E_ref_k  reference evaluation error: two roundings per product, one per sequential add,
-//            worst case over |p| <= 128 with the actual |COS_LUT products| as weights
-//   E_lut_k  six-decimal LUT vs the true cosines the fast path uses
-//   E_aan_k  first-order forward error bound of the float32 AAN flow graph, every add and
-//            multiply rounded separately (FMA contraction only lowers the true error)
-//   last     rounding of M_k, of the fma, and of the reference's final scale and division
+//   E_ref    reference evaluation error: two roundings per product, one per sequential add, worst case over |p| <= 128
+//            with the actual |COS_LUT products| as weights
+//   E_mfma   accumulation error of the matrix pipe in ANY summation order (see derive_mfma_tables)
+//   E_split  residual of the bf16 split of the LUT products
+//   last     rounding of K/q, of the fma, and of the reference's final scale and division
 //
-// tools/derive_guard.py holds the same derivation in Python; tests compare the two and
-// tests/test_guard_band.py checks the bound against brute-force float32 emulation.
+// tests/test_host.py::test_mfma_constants_are_on_the_safe_side pins the stored constants against the oracle's arithmetic.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -114,112 +112,10 @@ size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t
     return (size_t)(p - out);
 }
 
-// ---- forward error analysis of the AAN flow graph ------------------------------------------
 namespace {
 constexpr double kU = 5.9604644775390625e-08;   // 2^-24
 constexpr double kPmax = 128.0;
-
-struct Tracked {
-    double f[64];   // the exact linear functional of the 64 inputs this value represents
-    double e;       // bound on |float32 value - exact functional|
-    double bound() const { double s = 0; for (double x : f) s += std::fabs(x); return kPmax * s; }
-};
-
-Tracked combine(const Tracked &a, const Tracked &b, double sb) {
-    Tracked r;
-    for (int i = 0; i < 64; ++i) r.f[i] = a.f[i] + sb * b.f[i];
-    const double ein = a.e + b.e;
-    r.e = ein + kU * (r.bound() + ein) * 1.0000001;
-    return r;
-}
-Tracked add(const Tracked &a, const Tracked &b) { return combine(a, b, 1.0); }
-Tracked sub(const Tracked &a, const Tracked &b) { return combine(a, b, -1.0); }
-Tracked scale(const Tracked &a, double c) {
-    Tracked r;
-    for (int i = 0; i < 64; ++i) r.f[i] = a.f[i] * c;
-    const double ein = std::fabs(c) * a.e;
-    r.e = ein + 2.0 * kU * (r.bound() + ein) * 1.0000001;   // rounded constant, rounded product
-    return r;
-}
-
-void aan8_tracked(Tracked *d[8]) {
-    const double A1 = std::sqrt(0.5), A2 = std::cos(3 * M_PI / 8) * std::sqrt(2.0),
-                 A4 = std::cos(M_PI / 8) * std::sqrt(2.0), A5 = std::cos(3 * M_PI / 8);
-    Tracked t0 = add(*d[0], *d[7]), t7 = sub(*d[0], *d[7]);
-    Tracked t1 = add(*d[1], *d[6]), t6 = sub(*d[1], *d[6]);
-    Tracked t2 = add(*d[2], *d[5]), t5 = sub(*d[2], *d[5]);
-    Tracked t3 = add(*d[3], *d[4]), t4 = sub(*d[3], *d[4]);
-    Tracked e0 = add(t0, t3), e3 = sub(t0, t3), e1 = add(t1, t2), e2 = sub(t1, t2);
-    Tracked o_0 = add(e0, e1), o_4 = sub(e0, e1);
-    Tracked z1 = scale(add(e2, e3), A1);
-    Tracked o_2 = add(e3, z1), o_6 = sub(e3, z1);
-    Tracked q0 = add(t4, t5), q1 = add(t5, t6), q2 = add(t6, t7);
-    Tracked z5 = scale(sub(q0, q2), A5);
-    Tracked z2 = add(scale(q0, A2), z5), z4 = add(scale(q2, A4), z5);
-    Tracked z3 = scale(q1, A1);
-    Tracked z11 = add(t7, z3), z13 = sub(t7, z3);
-    *d[5] = add(z13, z2); *d[3] = sub(z13, z2); *d[1] = add(z11, z4); *d[7] = sub(z11, z4);
-    *d[0] = o_0; *d[4] = o_4; *d[2] = o_2; *d[6] = o_6;
-}
 }  // namespace
-
-void derive_quant_consts(const uint8_t table[64], QuantConsts *qc, double delta_out[64]) {
-    std::vector<Tracked> d(64);
-    for (int i = 0; i < 64; ++i) { std::memset(d[i].f, 0, sizeof(d[i].f)); d[i].f[i] = 1.0; d[i].e = 0.0; }
-    for (int r = 0; r < 8; ++r) { Tracked *p[8]; for (int c = 0; c < 8; ++c) p[c] = &d[r * 8 + c]; aan8_tracked(p); }
-    for (int c = 0; c < 8; ++c) { Tracked *p[8]; for (int r = 0; r < 8; ++r) p[r] = &d[r * 8 + c]; aan8_tracked(p); }
-
-    for (int k = 0; k < 64; ++k) {
-        const int u = k >> 3, v = k & 7;
-        double t_true[64], t_lut[64];
-        int imax = 0;
-        for (int x = 0; x < 8; ++x)
-            for (int y = 0; y < 8; ++y) {
-                t_true[x * 8 + y] = std::cos((2 * x + 1) * u * M_PI / 16) * std::cos((2 * y + 1) * v * M_PI / 16);
-                t_lut[x * 8 + y] = (double)kCosLut[x][u] * (double)kCosLut[y][v];
-                if (std::fabs(t_true[x * 8 + y]) > std::fabs(t_true[imax])) imax = x * 8 + y;
-            }
-        const double G = d[k].f[imax] / t_true[imax];
-        const float cu = u == 0 ? 0.707107f : 1.0f, cv = v == 0 ? 0.707107f : 1.0f;
-        const double K = (double)((0.25f * cu) * cv);                 // dct.c:87-93, float32 products
-        double wsum = 0, run = 0, adds = 0, elut = 0;
-        for (int j = 0; j < 64; ++j) {
-            const double w = std::fabs(t_lut[j]);
-            wsum += w;
-            run += w;
-            if (j >= 1) adds += run;
-            elut += std::fabs(t_lut[j] - t_true[j]);
-        }
-        const double e_ref = (2.0 * kU * kPmax * wsum + kU * kPmax * adds) * 1.001;
-        const double e_lut = kPmax * elut;
-        const double e_aan = d[k].e;
-        const double q = (double)table[k];
-        const double zmax = K * kPmax * wsum / q;
-        const double delta = (K / q) * (e_ref + e_lut) + (K / (q * std::fabs(G))) * e_aan + 4.0 * kU * (zmax + 1.0);
-        qc->mult[k] = (float)(K / (q * G));
-        // Stored float32 constants must stay on the safe side of delta after rounding:
-        // need (bias - 0.5) >= delta and thr >= (bias - 0.5) + delta.  ulp(0.5) = 6e-8.
-        qc->bias[k] = (float)(0.5 + delta * 1.001 + 1.0e-7);
-        const double db = (double)qc->bias[k] - 0.5;
-        qc->thr[k] = (float)(db + delta * 1.001 + 1.0e-7);
-        qc->qstep[k] = (float)table[k];
-        if (delta_out) delta_out[k] = delta;
-    }
-}
-
-void derive_std_consts(const uint8_t table[64], StdConsts *sc) {
-    QuantConsts qc;
-    double delta[64];
-    derive_quant_consts(table, &qc, delta);
-    double dmax = 0;
-    for (int k = 1; k < 64; ++k) dmax = delta[k] > dmax ? delta[k] : dmax;
-    sc->bias = (float)(0.5 + dmax * 1.001 + 1.0e-7);
-    const double db = (double)sc->bias - 0.5;          // >= every delta_k
-    for (int k = 0; k < 64; ++k) {
-        sc->mult[k] = qc.mult[k];
-        sc->thr[k] = (float)(db + delta[k] * 1.001 + 1.0e-7);
-    }
-}
 
 // ---- matrix-pipe tables ----------------------------------------------------------------------
 // out_z = sum_p Kmat[c][p] * pix[p], Kmat[c][p] = COS_LUT[x][u] * COS_LUT[y][v] (exact product of the two
@@ -246,11 +142,8 @@ double from_bf16(uint16_t b) {
 }
 }  // namespace
 
-void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64], bool grouped) {
+void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64]) {
     std::memset(mt, 0, sizeof(*mt));
-    QuantConsts qc;
-    double delta_aan[64];
-    derive_quant_consts(table, &qc, delta_aan);        // for K_k, e_ref reuse we recompute below
     uint16_t *af = reinterpret_cast<uint16_t *>(mt->afrag);
     double delta_z[64];
     double dmax = 0;
@@ -268,18 +161,17 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
                 const uint16_t lo = to_bf16(r2);
                 term[0][p] = from_bf16(lo); term[1][p] = from_bf16(mid); term[2][p] = from_bf16(hi);
                 split_res += std::fabs(kmat[p] - (term[0][p] + term[1][p] + term[2][p]));
-                // scatter into the A-operand order: chain H, matrix row R, k-step s, lane (hk, R), element j
-                // half-major (fused kernel): lane half h = z >> 5 holds z = 32h + 16H + r in accumulator H, register r;
-                // grouped (split pipeline): lane half h = (z >> 3) & 1 holds z = 16G + 8h + j at site 8G + j = 16H + r
-                const int site = grouped ? 8 * (z >> 4) + (z & 7) : (z & 31);
-                const int h = grouped ? (z >> 3) & 1 : z >> 5, H = site >> 4, r = site & 15;
+                // scatter into the A-operand order: chain H, matrix row R, k-step s, lane (hk, R), element j;
+                // lane half h = (z >> 3) & 1 holds z = 16G + 8h + j at site 8G + j = 16H + r
+                const int site = 8 * (z >> 4) + (z & 7);
+                const int h = (z >> 3) & 1, H = site >> 4, r = site & 15;
                 const int R = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int s = p >> 4, hk = (p >> 3) & 1, j = p & 7;
                 const int lane = 32 * hk + R;
                 const uint16_t t3[3] = {lo, mid, hi};
                 for (int t = 0; t < 3; ++t) af[((((size_t)t * 2 + H) * 4 + s) * 64 + lane) * 8 + j] = t3[t];
             }
-        // reference evaluation error (same expression as derive_quant_consts)
+        // reference evaluation error: two roundings per product, 63 sequential float32 additions (dct.c:84)
         double wsum = 0, run = 0, adds = 0;
         for (int j = 0; j < 64; ++j) { const double w = std::fabs(kmat[j]); wsum += w; run += w; if (j >= 1) adds += run; }
         const double e_ref = (2.0 * kU * kPmax * wsum + kU * kPmax * adds) * 1.001;
@@ -324,16 +216,6 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
 void cos_lut_copy(float out[64]) {
     for (int x = 0; x < 8; ++x)
         for (int u = 0; u < 8; ++u) out[x * 8 + u] = kCosLut[x][u];
-}
-
-#include "std_table_consts.inc"
-
-bool std_consts_match_baked(const uint8_t table[64]) {
-    if (std::memcmp(table, kStdTable, 64) != 0) return false;
-    StdConsts sc;
-    derive_std_consts(table, &sc);
-    return std::memcmp(sc.mult, kStdMult, sizeof(kStdMult)) == 0 && std::memcmp(sc.thr, kStdThr, sizeof(kStdThr)) == 0 &&
-           sc.bias == kStdBias;
 }
 
 }  // namespace jpegamd

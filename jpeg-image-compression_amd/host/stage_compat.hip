@@ -190,12 +190,6 @@ __global__ void k_st_pack(const RLESymbol *__restrict__ sym, const uint8_t *__re
     if ((uint32_t)placed) atomicOr(&words[w + 1], (uint32_t)placed);
 }
 
-__global__ void k_st_segbits(uint32_t *seg_bits, int nseg, unsigned long long total_bits) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= nseg) return;
-    const unsigned long long lo = (unsigned long long)i * 8192ull;
-    seg_bits[i] = (uint32_t)(total_bits - lo < 8192ull ? total_bits - lo : 8192ull);
-}
 
 template <typename S>
 S *make_struct() { return (S *)std::calloc(1, sizeof(S)); }
@@ -300,6 +294,23 @@ extern "C" ZigZagData *performZigZag(const QuantizedImage *qImg) {
     return z;
 }
 
+// Byte stuffing of an MSB-first bit string held in 32-bit words: a piece is 64 output-independent bytes.
+// kWrite == false: ffoff[piece] = its 0xFF count;  kWrite == true: ffoff holds the exclusive sums, bytes go out.
+template <bool kWrite>
+__global__ void k_st_stuff(const uint32_t *__restrict__ words, unsigned long long nbytes, size_t npieces,
+                           unsigned long long *__restrict__ ffoff, uint8_t *__restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npieces) return;
+    const unsigned long long b0 = (unsigned long long)p * 64ull, b1 = b0 + 64ull < nbytes ? b0 + 64ull : nbytes;
+    unsigned long long pos = kWrite ? b0 + ffoff[p] : 0ull, cnt = 0;
+    for (unsigned long long i = b0; i < b1; ++i) {
+        const uint8_t v = (uint8_t)(words[i >> 2] >> (24u - 8u * (uint32_t)(i & 3ull)));
+        if (kWrite) { out[pos++] = v; if (v == 0xFF) out[pos++] = 0x00; }      // huffman.c:29-31
+        else cnt += v == 0xFF;
+    }
+    if (!kWrite) ffoff[p] = cnt;
+}
+
 static bool exclusive_sum(unsigned long long *d, size_t n) {     // in place; d has n + 1 slots, d[n] receives the total
     size_t tmp_bytes = 0;
     if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d, d, (int)(n + 1)) != hipSuccess) return false;
@@ -345,30 +356,24 @@ extern "C" JpegEncoderBuffer *encodeHuffman(const RLEData *rle, int totalBlocks)
     unsigned long long total_bits = 0;
     if (hipGetLastError() != hipSuccess || !exclusive_sum(off.p, (size_t)n) ||
         hipMemcpy(&total_bits, off.p + n, sizeof(total_bits), hipMemcpyDeviceToHost) != hipSuccess) ST_FAIL(b, freeJpegEncoderBuffer);
-    // the packed bit string, cut into 8192-bit pieces, IS the segment layout of the finalize kernels (stride 256 words)
-    const int nseg = (int)((total_bits + 8191ull) / 8192ull);
-    const size_t nwords = (size_t)(nseg > 0 ? nseg : 1) * 256 + 2;
-    const uint64_t out_cap = 2 * ((total_bits + 7) / 8) + 16;
-    Dev<uint32_t> words, seg_bits, seg_ff, chunk_ff; Dev<unsigned long long> chunk_b0; Dev<uint8_t> out; Dev<uint64_t> out_size; Dev<ScanStats> stats;
-    const int nchunks = finalize_chunks(nseg > 0 ? nseg : 1);
-    if (!words.alloc(nwords) || hipMemset(words.p, 0, nwords * sizeof(uint32_t)) != hipSuccess || !seg_bits.alloc((size_t)(nseg > 0 ? nseg : 1) + 16) ||
-        hipMemset(seg_bits.p, 0, ((size_t)(nseg > 0 ? nseg : 1) + 16) * sizeof(uint32_t)) != hipSuccess ||
-        !seg_ff.alloc((size_t)(nseg > 0 ? nseg : 1)) || !chunk_ff.alloc((size_t)nchunks + 1) || !chunk_b0.alloc((size_t)nchunks + 1) ||
-        !out.alloc((size_t)out_cap) || !out_size.alloc(1) || !stats.alloc(1) || hipMemset(stats.p, 0, sizeof(ScanStats)) != hipSuccess ||
-        hipMemset(out_size.p, 0, sizeof(uint64_t)) != hipSuccess) ST_FAIL(b, freeJpegEncoderBuffer);
+    // byte stuffing of the packed string (huffman.c:26-32): 0xFF count per 64-byte piece, exclusive sum, write
+    const unsigned long long nbytes = (total_bits + 7ull) / 8ull;           // the last byte is zero-padded (huffman.c:65-81)
+    const size_t npieces = (size_t)((nbytes + 63ull) / 64ull);
+    const size_t nwords = (size_t)((nbytes + 3ull) / 4ull) + 2;
+    const uint64_t out_cap = 2 * nbytes + 16;
+    Dev<uint32_t> words; Dev<unsigned long long> ffoff; Dev<uint8_t> out;
+    if (!words.alloc(nwords) || hipMemset(words.p, 0, nwords * sizeof(uint32_t)) != hipSuccess || !ffoff.alloc(npieces + 1) ||
+        hipMemset(ffoff.p, 0, (npieces + 1) * sizeof(unsigned long long)) != hipSuccess || !out.alloc((size_t)out_cap)) ST_FAIL(b, freeJpegEncoderBuffer);
     uint64_t size = 0;
-    if (nseg > 0) {
+    if (nbytes > 0) {
         hipLaunchKernelGGL(k_st_pack, dim3(grid_for((size_t)n)), dim3(256), 0, nullptr, sym.p, kind.p, n, huff.p, off.p, words.p);
-        hipLaunchKernelGGL(k_st_segbits, dim3(grid_for((size_t)nseg)), dim3(256), 0, nullptr, seg_bits.p, nseg, total_bits);
-        FinalizeArgs fa;
-        std::memset(&fa, 0, sizeof(fa));
-        fa.seg_words = words.p; fa.seg_stride = 256; fa.seg_bits = seg_bits.p; fa.seg_tail = nullptr;
-        fa.num_segs = nseg; fa.num_chunks = nchunks;
-        fa.out = out.p; fa.out_capacity = out_cap; fa.out_size = out_size.p; fa.stats = stats.p;
-        fa.prefix = nullptr; fa.prefix_len = 0; fa.write_eoi = 0;
-        fa.seg_ff = seg_ff.p; fa.chunk_ff = chunk_ff.p; fa.chunk_b0 = chunk_b0.p;
-        if (hipGetLastError() != hipSuccess || launch_finalize(fa, nullptr) != 0 ||
-            hipMemcpy(&size, out_size.p, sizeof(size), hipMemcpyDeviceToHost) != hipSuccess || size > out_cap) ST_FAIL(b, freeJpegEncoderBuffer);
+        hipLaunchKernelGGL((k_st_stuff<false>), dim3(grid_for(npieces)), dim3(256), 0, nullptr, words.p, nbytes, npieces, ffoff.p, out.p);
+        unsigned long long total_ff = 0;
+        if (hipGetLastError() != hipSuccess || !exclusive_sum(ffoff.p, npieces) ||
+            hipMemcpy(&total_ff, ffoff.p + npieces, sizeof(total_ff), hipMemcpyDeviceToHost) != hipSuccess) ST_FAIL(b, freeJpegEncoderBuffer);
+        hipLaunchKernelGGL((k_st_stuff<true>), dim3(grid_for(npieces)), dim3(256), 0, nullptr, words.p, nbytes, npieces, ffoff.p, out.p);
+        size = nbytes + total_ff;
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess || size > out_cap) ST_FAIL(b, freeJpegEncoderBuffer);
     }
     b->size = b->capacity = (size_t)size;
     b->data = (uint8_t *)std::malloc(size ? (size_t)size : 1);

@@ -74,7 +74,8 @@ def _load() -> C.CDLL:
         "jpegamd_debug_dct_exact": (i32, [vp, vp, vp, i64]),
         "jpegamd_synth_bmp": (u64, [i32, i32, C.c_uint32, i32, C.c_uint32, vp, u64]),
         "jpegamd_version": (C.c_char_p, []),
-        "jpegamd_debug_quant_consts": (i32, [i32, vp, vp, vp, vp, vp]),
+        "jpegamd_debug_quant_table": (i32, [i32, vp]),
+        "jpegamd_segment_meta_words": (i32, []),
         "jpegamd_debug_mfma_consts": (i32, [i32, vp, vp, vp, vp]),
         "jpegamd_debug_group_thresholds": (i32, [i32, vp]),
         "jpegamd_debug_cos_lut": (i32, [vp]),
@@ -102,20 +103,21 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async "
             "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
-            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_consts jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
+            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_table jpegamd_segment_meta_words jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
             "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files "
             "jpegamd_encode_rows_async jpegamd_export_segments jpegamd_import_segments jpegamd_finalize_async").split()
 
 
-def quant_consts(quality: int = 50):
-    """-> dict of numpy arrays (mult, bias, thr float32[64]; delta float64[64]; table uint8[64])."""
+def quant_table(quality: int = 50):
+    """uint8[64], raster order: the reference's table (quality 50) or its libjpeg scaling."""
     import numpy as np
-    mult, bias, thr = (np.zeros(64, np.float32) for _ in range(3))
-    delta, table = np.zeros(64, np.float64), np.zeros(64, np.uint8)
-    lib.jpegamd_debug_quant_consts(quality, mult.ctypes.data, bias.ctypes.data, thr.ctypes.data, delta.ctypes.data,
-                                   table.ctypes.data)
-    return dict(mult=mult, bias=bias, thr=thr, delta=delta, table=table)
+    table = np.zeros(64, np.uint8)
+    lib.jpegamd_debug_quant_table(quality, table.ctypes.data)
+    return table
+
+
+SEG_META_WORDS = int(lib.jpegamd_segment_meta_words())      # metadata words per segment in the sharded-image exchange
 
 
 def mfma_consts(quality: int = 50):

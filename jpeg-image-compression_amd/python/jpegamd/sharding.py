@@ -187,11 +187,17 @@ class ShardedImageEncoder:
             max_words = nseg * ((256 * 1721 + 31) // 32 + 1)          # every block at the worst-case bit count
         self.max_words, self.max_segs = int(max_words), nseg
         self.dense = torch.empty(self.max_words, dtype=torch.int32, device=device)
-        self.meta = torch.zeros(nseg * 8, dtype=torch.int32, device=device)
+        self.meta_words = self._meta_words()
+        self.meta = torch.zeros(nseg * self.meta_words, dtype=torch.int32, device=device)
         self.total = torch.zeros(1, dtype=torch.int32, device=device)
         if self.rank == dst and self.world > 1:
             self.recv_dense = [torch.empty(self.max_words, dtype=torch.int32, device=device) for _ in range(self.world)]
-            self.recv_meta = [torch.empty(nseg * 8, dtype=torch.int32, device=device) for _ in range(self.world)]
+            self.recv_meta = [torch.empty(nseg * self.meta_words, dtype=torch.int32, device=device) for _ in range(self.world)]
+
+    @staticmethod
+    def _meta_words() -> int:
+        import jpegamd
+        return jpegamd.SEG_META_WORDS
 
     def rows_of(self, rank: int) -> Tuple[int, int]:
         return shard_range(self.blocks_h, self.world, rank)
@@ -232,7 +238,7 @@ def encode_image_virtual_ranks(jpegamd, img, width: int, height: int, ranks: int
         nseg = max(1, (b1 - b0) * spr)
         words = nseg * ((256 * 1721 + 31) // 32 + 1)
         dense = torch.empty(words, dtype=torch.int32, device=device)
-        meta = torch.zeros(nseg * 8, dtype=torch.int32, device=device)
+        meta = torch.zeros(nseg * jpegamd.SEG_META_WORDS, dtype=torch.int32, device=device)
         total = torch.zeros(1, dtype=torch.int32, device=device)
         enc.encode_rows_async(img, b0, b1, 0)
         enc.export_segments(img, b0, b1, dense.data_ptr(), words, meta.data_ptr(), total.data_ptr(), 0)

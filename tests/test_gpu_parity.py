@@ -429,22 +429,6 @@ def test_stage_functions_match_the_oracle_stage_by_stage(jpegamd, oracle, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [{"JPEGAMD_KERNEL": "mfma-fused"}, {"JPEGAMD_KERNEL": "aan"}, {"JPEGAMD_KERNEL": "generic"},
-                                     {"JPEGAMD_KERNEL": "aan", "JPEGAMD_POST": "split"}, {"JPEGAMD_KERNEL": "aan", "JPEGAMD_ENTROPY": "lane"}],
-                         ids=lambda v: "+".join(f"{k[8:].lower()}={x}" for k, x in v.items()))
-def test_retained_kernel_variants_stay_bit_exact(jpegamd, oracle, dev, variant, monkeypatch):
-    """The earlier kernels kept behind environment switches (read when an encoder context is created) share the host
-    layer, the tables and the finalize with the default pipeline: they must keep producing the oracle's bytes."""
-    for k, v in variant.items():
-        monkeypatch.setenv(k, v)
-    enc = jpegamd.Encoder(1024, 768)
-    for (w, h, seed, kind, flags) in [(640, 480, 6, 3, 2), (203, 117, 5, 1, 0), (1024, 768, 7, 0, 0), (8, 8, 1, 2, 0), (520, 16, 9, 1, 0)]:
-        bmp = jpegamd.synth_bmp(w, h, seed, kind, flags)
-        got, _ = device_encode(jpegamd, enc, bmp, dev)
-        assert got == oracle.encode_bmp(bmp), (variant, w, h, kind)
-
-
-@pytest.mark.gpu
 def test_concurrent_streams_and_contexts(jpegamd, oracle, dev):
     """bench.py's default mode: several encoder contexts on several HIP streams with many encodes in flight and no host
     synchronisation in between.  Every output (not only the last) must equal the oracle's."""

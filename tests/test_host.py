@@ -79,24 +79,34 @@ def test_parse_bmp_follows_reference_rules(jpegamd):
         jpegamd.parse_bmp(b"PM" + bmp[2:])          # magic (bmp_handler.c:30)
 
 
-def test_quant_constants_match_python_derivation(jpegamd):
-    import derive_guard as dg
-    for q in (50, 10, 90):
-        table = [int(x) for x in jpegamd.quant_consts(q)["table"]]
-        ref = dg.derive(table)
-        c = jpegamd.quant_consts(q)
-        assert np.allclose(c["delta"], [r["delta"] for r in ref], rtol=1e-9, atol=0)
-        assert np.allclose(c["mult"], [r["M"] for r in ref], rtol=2e-7, atol=0)
-        d = c["delta"]
-        assert np.all(c["bias"].astype(np.float64) - 0.5 >= d) and np.all(c["thr"].astype(np.float64) >= (c["bias"].astype(np.float64) - 0.5) + d)
-    t50 = jpegamd.quant_consts(50)["table"]
-    assert list(t50[:8]) == [16, 11, 10, 16, 24, 40, 51, 61] and list(jpegamd.quant_consts(0)["table"]) == list(t50)
+def test_quant_table_for_quality(jpegamd, oracle):
+    t50 = jpegamd.quant_table(50)
+    assert list(t50[:8]) == [16, 11, 10, 16, 24, 40, 51, 61] and list(jpegamd.quant_table(0)) == list(t50)   # jpeg_tables.c:3-12
+    for q in (1, 10, 50, 90, 100):
+        assert list(jpegamd.quant_table(q)) == [int(x) for x in oracle.quant_table(q)]
+
+
+def test_constants_derivation_is_reentrant(jpegamd):
+    """Contexts may be driven from different host threads (one in-flight call per context): the table derivation must not
+    share static scratch.  Two threads derive different qualities concurrently; results equal the single-threaded ones."""
+    import threading
+    want = {q: jpegamd.mfma_consts(q) for q in (10, 90)}
+    bad = []
+
+    def work(q):
+        for _ in range(40):
+            c = jpegamd.mfma_consts(q)
+            if not (np.array_equal(c["qmul"], want[q]["qmul"]) and np.array_equal(c["qthr"], want[q]["qthr"]) and c["bias"] == want[q]["bias"]):
+                bad.append(q)
+    ts = [threading.Thread(target=work, args=(q,)) for q in (10, 90, 10, 90)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
 
 
 def test_mfma_constants_are_on_the_safe_side(jpegamd, oracle):
     """Matrix-pipe kernel: threshold >= (bias - 0.5) + delta for every coefficient, bias - 0.5 >= every delta, the
-    multiplier is K/q (the MFMA output is the plain LUT sum), and delta is never below the reference-evaluation
-    part of the AAN kernel's bound minus its LUT term (the MFMA path evaluates the LUT products themselves)."""
+    multiplier is K/q (the MFMA output is the plain LUT sum)."""
     zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
     for q in (50, 10, 90):
@@ -199,49 +209,6 @@ def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
                 assert np.abs(z_fast - z_ref).max() <= c["delta"][k], (q, order, z)
                 unflagged += int((~flagged).sum())
             assert unflagged > 0.9 * acc.size
-
-
-def test_guard_band_holds_on_float32_emulation(jpegamd, oracle):
-    """Emulate the kernel's fast path in numpy float32 (every op rounded separately: the worst case for
-    the bound) and check against the oracle: a coefficient the guard does NOT flag must already equal the
-    reference's quantised value, and the observed |z_fast - r_ref| must stay below delta_k."""
-    c = jpegamd.quant_consts(50)
-    f32 = np.float32
-    A1, A2, A4, A5 = f32(0.70710678118654752), f32(0.54119610014619698), f32(1.30656296487637653), f32(0.38268343236508977)
-
-    def aan8(d):
-        t0, t7, t1, t6 = d[0] + d[7], d[0] - d[7], d[1] + d[6], d[1] - d[6]
-        t2, t5, t3, t4 = d[2] + d[5], d[2] - d[5], d[3] + d[4], d[3] - d[4]
-        e0, e3, e1, e2 = t0 + t3, t0 - t3, t1 + t2, t1 - t2
-        z1 = (e2 + e3) * A1
-        o0, o1, o2 = t4 + t5, t5 + t6, t6 + t7
-        z5 = (o0 - o2) * A5
-        z2, z4, z3 = o0 * A2 + z5, o2 * A4 + z5, o1 * A1
-        z11, z13 = t7 + z3, t7 - z3
-        return [e0 + e1, z11 + z4, e3 + z1, z13 - z2, e0 - e1, z13 + z2, e3 - z1, z11 - z4]
-
-    checked = flagged = 0
-    worst = 0.0
-    for (w, h, seed, kind) in [(256, 256, 3, 0), (256, 128, 9, 1), (128, 128, 101, 2), (192, 64, 0, 3)]:
-        st = oracle.stages(jpegamd.synth_bmp(w, h, seed, kind, 0))
-        ph, pw = st["y"].shape
-        blk = lambda a: a.reshape(ph // 8, 8, pw // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 8, 8)
-        y, q, dref = blk(st["y"]).astype(f32), blk(st["quant"]).astype(np.int64), blk(st["dct"]).astype(np.float64)
-        d = np.stack(aan8([y[:, :, i] for i in range(8)]), axis=2)
-        d = np.stack(aan8([d[:, i, :] for i in range(8)]), axis=1)
-        mult, bias, thr = (c[k].reshape(8, 8) for k in ("mult", "bias", "thr"))
-        zc = (d * mult + bias).astype(f32)
-        fl = np.floor(zc)
-        flag = (zc - fl) <= thr
-        flag[:, 0, 0] = True                           # DC always takes the exact integer path
-        assert np.array_equal(fl.astype(np.int64)[~flag], q[~flag])
-        err = np.abs(d.astype(np.float64) * mult.astype(np.float64) - dref / c["table"].reshape(8, 8)) / c["delta"].reshape(8, 8)
-        err[:, 0, 0] = 0
-        worst = max(worst, float(err.max()))
-        checked += flag.size
-        flagged += int(flag.sum()) - flag.shape[0]
-    assert worst < 1.0, f"observed fast-path error reached {worst:.3f} of the rigorous bound"
-    assert flagged < 0.002 * checked               # the exact path stays rare (~0.01-0.04 % here)
 
 
 def test_max_jfif_bytes_bounds_the_worst_case(jpegamd):

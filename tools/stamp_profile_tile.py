@@ -55,3 +55,14 @@ print(f"kernel span seen by the waves: {span:.2f} us; entry spread {(rt[:, 0].ma
       f"first wave done at {(rt[:, 2].min() - rt[:, 0].min()) / 100.0:.2f} us")
 clk = buf[:, 11].astype(np.float64) / np.maximum(rt[:, 2] - rt[:, 1], 1.0) * 0.1
 print(f"shader clock inside the loop: mean {clk.mean():.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})")
+# end-of-kernel balance: when do the ticket groups (blockIdx & 63) and the XCDs (blockIdx % 8) run dry?
+blk = np.arange(nwaves) // 8
+t0 = rt[:, 0].min()
+end = (rt[:, 2] - t0) / 100.0
+grp_end = np.array([end[(blk & 63) == g].max() for g in range(64)])
+grp_first = np.array([end[(blk & 63) == g].min() for g in range(64)])
+print(f"group end times (us): min {grp_end.min():.2f} mean {grp_end.mean():.2f} max {grp_end.max():.2f}; first wave of a group done: min {grp_first.min():.2f} mean {grp_first.mean():.2f}")
+for x in range(8):
+    m = (blk % 8) == x
+    print(f"  xcd-slot {x}: clock {clk[m].mean():.3f} GHz  waves end mean {end[m].mean():.2f} max {end[m].max():.2f} us")
+print(f"idle SIMD-time at the end: {(end.max() - end).mean():.2f} us per wave of {end.max():.2f} ({100 * (end.max() - end).mean() / end.max():.1f} %)")
