@@ -22,7 +22,7 @@ namespace jpegamd {
 constexpr int kWavesE = 4;
 constexpr int kSegBufWords = 512;               // LDS bit window per wave (typical segment: ~180 words); flushed when nearly full
 constexpr int kBatchItems = 128;
-constexpr uint32_t kBatchMaxWords = (kBatchItems * 60 + 31) / 32 + 2;   // a symbol with three ZRLs is <= 60 bits
+
 
 // lanes >= first (first in 0..64) of a full wave
 __device__ __forceinline__ unsigned long long lanes_from(int first) {
@@ -51,21 +51,28 @@ struct Sym {            // one coded symbol: left-aligned code + amplitude bits,
     uint32_t zrl;       // 0..3
 };
 
+// Code table in LDS, by symbol (AC: run << 4 | size; DC: 256 + size): bits 31..5 = the Huffman code LEFT-ALIGNED,
+// bits 4..0 = code length + size, i.e. the length of code + amplitude bits.  Symbols without a code hold 0.
+__device__ __forceinline__ uint32_t table_entry(uint32_t word /*(len << 16) | code, quant_consts.cpp*/, uint32_t size) {
+    const uint32_t clen = word >> 16, code = word & 0xFFFFu;
+    return clen ? ((code << (27u - clen)) << 5) | (clen + size) : 0u;
+}
+
 // item -> symbol.  `prev` is the item in front of it in the stream (only its position field is used, and only for a
 // non-zero AC item, whose predecessor is always an item of the same block).
 __device__ __forceinline__ Sym code_item(uint32_t it, int v /*its value: (int16) it, minus the DC predictor for a tile's first item*/,
-                                         uint32_t prev, const uint32_t *s_huff) {
+                                         uint32_t prev, const uint32_t *s_tab) {
     const bool isdc = (int)it < 0;
     const int w = v + (v >> 31);                                              // rle.c:24-35: v, or v - 1 when negative
-    const int nb = 31 - leading_sign_bits((w << 1) | 1);                 // rle.c:9-22 without the abs / zero special cases
+    const int nb = 31 - leading_sign_bits((w << 1) | 1);                      // rle.c:9-22 without the abs / zero special cases
     const uint32_t amp = __builtin_amdgcn_ubfe((uint32_t)w, 0u, (uint32_t)nb);
     const int gap = (int)((it >> 16) & 0x7Fu) - (int)((prev >> 16) & 0x7Fu) - 1;
-    const int run = (v != 0 && !isdc) ? gap : 0;                              // EOB item: value 0 -> symbol 0x00 (rle.c:121-123)
-    const uint32_t sym = isdc ? (uint32_t)(256 + nb) : (uint32_t)(((run & 15) << 4) | nb);
-    const uint32_t hc = s_huff[(it & kItNop) ? 272u : sym];
+    const int run = isdc ? 0 : gap;                                           // a non-DC item is a non-zero AC coefficient (EOB: kItEobValue)
+    const uint32_t sym = (isdc ? 256u : (uint32_t)((run & 15) << 4)) | (uint32_t)nb;
+    const uint32_t e = s_tab[sym];
     Sym s;
-    s.len = (hc >> 16) + (uint32_t)nb;
-    s.bits = (((hc & 0xFFFFu) << nb) | amp) << ((32u - s.len) & 31u);        // len == 0: code 0, no amplitude -> bits 0
+    s.len = e & 31u;
+    s.bits = (e & ~31u) | (amp << ((32u - s.len) & 31u));                     // amplitude right behind the code (huffman.c:145-153,176-186)
     s.zrl = (uint32_t)run >> 4;                                               // rle.c:99-103
     return s;
 }
@@ -88,12 +95,12 @@ __device__ __forceinline__ uint32_t ones8_starts(uint32_t cur, uint32_t nxt) {
 }
 
 __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
-    __shared__ uint32_t s_huff[288];                // [0,256) AC, [256,272) DC, [272,288) zero-length codes
+    __shared__ uint32_t s_huff[288];                // [0,256) AC, [256,272) DC sizes 0..15 (12: padding item, no code; 13: EOB)
     __shared__ uint32_t s_win[kWavesE][kSegBufWords + 8];
     {
         const int t = (int)threadIdx.x;
-        s_huff[t] = a.huff[t];
-        if (t < 32) s_huff[256 + t] = t < 16 ? a.huff[256 + t] : 0u;
+        s_huff[t] = table_entry(a.huff[t], (uint32_t)t & 15u);
+        if (t < 32) s_huff[256 + t] = t == 13 ? table_entry(a.huff[0], 0u) /*EOB, symbol 0x00*/ : t < 16 ? table_entry(a.huff[256 + t], (uint32_t)t) : 0u;
     }
     __syncthreads();
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -126,42 +133,49 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         const_cast<uint32_t *>(a.tile_items + (size_t)tile0 * kTileItemCap), 0, ntiles * kTileItemCap * 4, 0x00020000);
     const uint32_t lane8 = (uint32_t)lane * 8u;
 
-    // Wave-uniform plan of one batch: which tile the window starts in, where the (at most two) later tiles begin.
-    struct Plan {
-        uint32_t soff;              // scalar byte offset of the window's first item in its own tile's terms
-        int l1, l2;                 // first lane of the 2nd / 3rd tile inside the window (64: none)
-        uint32_t dk1, dk2;          // address deltas from those lanes on
-        int f0;                     // lane 0 starts a tile
-        uint32_t d0, d1, d2;        // DC predictors of the tiles starting at lane 0 / l1 / l2
-        int nvalid;                 // lanes holding items of the stream
-        int t_next;                 // tile the next window starts in
+    // Plans of the batches.  Everything about a batch of 128 stream items that is wave-uniform -- the tile its window starts
+    // in, the lanes at which the (at most two) later tiles begin, the address steps there, the DC predictors of the tiles
+    // that start inside it -- is computed for 64 batches at once, batch b of the chunk in lane b, and fetched with six
+    // v_readlane per batch.  (Only a row's last tile can hold fewer than 64 items, so a window never meets a third start.)
+    uint32_t f_soff, f_dk1, f_dk2, f_lanes, f_d01, f_d2;
+    uint32_t tstart[kSegTiles];                                   // stream index of every tile's first item (total beyond the last)
+#pragma unroll
+    for (int t = 0; t < kSegTiles; ++t) tstart[t] = (uint32_t)__builtin_amdgcn_readlane((int)pstart, t);
+    const auto make_plans = [&](uint32_t first_batch) {
+        const uint32_t g0 = (first_batch + (uint32_t)lane) * (uint32_t)kBatchItems;
+        uint32_t t0 = 0;
+#pragma unroll
+        for (int t = 1; t < kSegTiles; ++t) t0 += (g0 >= tstart[t] && t < ntiles) ? 1u : 0u;
+        const auto of_tile = [&](uint32_t v, uint32_t t) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(t * 4u), (int)v); };
+        const uint32_t s0 = of_tile(pstart, t0), b1 = of_tile(pstart, t0 + 1u), b2 = of_tile(pstart, t0 + 2u);   // lanes >= ntiles hold `total`
+        const uint32_t k0 = of_tile(kdelta, t0), k1 = of_tile(kdelta, t0 + 1u), k2 = of_tile(kdelta, t0 + 2u);
+        const uint32_t end = g0 + (uint32_t)kBatchItems;
+        const uint32_t l1 = (b1 < end && b1 < total) ? (b1 - g0) >> 1 : 64u;
+        const uint32_t l2 = (b2 < end && b2 < total) ? (b2 - g0) >> 1 : 64u;
+        const uint32_t left = total - g0;                         // only batches with g0 < total are ever fetched
+        const uint32_t nvalid = left >= (uint32_t)kBatchItems ? 64u : left >> 1;
+        f_soff = g0 * 4u + k0;
+        f_dk1 = k1 - k0;
+        f_dk2 = k2 - k1;
+        f_lanes = l1 | (l2 << 8) | (nvalid << 16) | ((s0 == g0 ? 1u : 0u) << 24);
+        f_d01 = (of_tile(tprev, t0) & 0xFFFFu) | (of_tile(tprev, t0 + 1u) << 16);
+        f_d2 = of_tile(tprev, t0 + 2u);
     };
-    const auto plan = [&](uint32_t g0, int t0) {
+    struct Plan {
+        uint32_t soff, dk1, dk2;    // scalar byte offset of the window's first item; address steps at the later tiles' first lanes
+        int l1, l2, nvalid, f0;     // first lane of the 2nd / 3rd tile in the window (64: none); lanes holding items; lane 0 starts a tile
+        int d0, d1, d2;             // DC predictors of the tiles starting at lane 0 / l1 / l2 (rle.c:59-70)
+    };
+    const auto fetch_plan = [&](uint32_t b /*batch index inside the chunk*/) {
         Plan p;
-        const auto start_of = [&](int t) { return t < ntiles ? (uint32_t)__builtin_amdgcn_readlane((int)pstart, t) : total; };
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)kdelta, t0);
-        p.soff = g0 * 4u + k0;
-        p.f0 = start_of(t0) == g0;
-        p.d0 = (uint32_t)__builtin_amdgcn_readlane((int)tprev, t0);
-        const uint32_t b1 = start_of(t0 + 1), b2 = start_of(t0 + 2), end = g0 + (uint32_t)kBatchItems;
-        p.l1 = (t0 + 1 < ntiles && b1 < end) ? (int)((b1 - g0) >> 1) : 64;
-        p.l2 = (t0 + 2 < ntiles && b2 < end) ? (int)((b2 - g0) >> 1) : 64;
-        p.dk1 = p.dk2 = p.d1 = p.d2 = 0u;
-        p.t_next = t0;
-        if (p.l1 < 64) {
-            const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)kdelta, t0 + 1);
-            p.dk1 = k1 - k0;
-            p.d1 = (uint32_t)__builtin_amdgcn_readlane((int)tprev, t0 + 1);
-            p.t_next = t0 + 1;
-            if (p.l2 < 64) {
-                p.dk2 = (uint32_t)__builtin_amdgcn_readlane((int)kdelta, t0 + 2) - k1;
-                p.d2 = (uint32_t)__builtin_amdgcn_readlane((int)tprev, t0 + 2);
-                p.t_next = t0 + 2;
-            }
-        }
-        // a tile that ends exactly at the window's end: the next window starts in the tile after it
-        if (start_of(p.t_next + 1) <= end && p.t_next + 1 < ntiles) ++p.t_next;
-        p.nvalid = total - g0 >= (uint32_t)kBatchItems ? 64 : (int)((total - g0) >> 1);
+        p.soff = (uint32_t)__builtin_amdgcn_readlane((int)f_soff, (int)b);
+        p.dk1 = (uint32_t)__builtin_amdgcn_readlane((int)f_dk1, (int)b);
+        p.dk2 = (uint32_t)__builtin_amdgcn_readlane((int)f_dk2, (int)b);
+        const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)f_lanes, (int)b);
+        const uint32_t d01 = (uint32_t)__builtin_amdgcn_readlane((int)f_d01, (int)b);
+        p.l1 = (int)(ln & 0xFFu); p.l2 = (int)((ln >> 8) & 0xFFu); p.nvalid = (int)((ln >> 16) & 0xFFu); p.f0 = (int)(ln >> 24);
+        p.d0 = (int)(short)(d01 & 0xFFFFu); p.d1 = (int)(short)(d01 >> 16);
+        p.d2 = (int)(short)((uint32_t)__builtin_amdgcn_readlane((int)f_d2, (int)b) & 0xFFFFu);
         return p;
     };
     const auto request = [&](const Plan &p) {
@@ -198,28 +212,31 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         }
     };
 
-    Plan cur = plan(0u, 0);
+    uint32_t *const segw = a.seg.words + (size_t)seg * kSegCapWords;
+    const uint32_t nbatches = (total + (uint32_t)kBatchItems - 1u) / (uint32_t)kBatchItems;
+    make_plans(0u);
+    Plan cur = fetch_plan(0u);
     auto nx = request(cur);
-    uint32_t g0 = 0;
     uint32_t prev_b = 0;                                          // second item of the lane before lane 0: the previous batch's last item
 #pragma unroll 1
-    while (g0 < total) {
+    for (uint32_t batch = 0; batch < nbatches; ++batch) {
         const auto items = nx;
         const Plan pl = cur;
-        const uint32_t g0n = g0 + (uint32_t)kBatchItems;
-        if (g0n < total) {                                        // next batch's loads in flight while this one is coded
-            cur = plan(g0n, pl.t_next);
+        if (batch + 1u < nbatches) {                              // next batch's loads in flight while this one is coded
+            if (((batch + 1u) & 63u) == 0u) make_plans(batch + 1u);
+            cur = fetch_plan((batch + 1u) & 63u);
             nx = request(cur);
         }
-        g0 = g0n;
         uint32_t ia = (uint32_t)items[0], ib = (uint32_t)items[1];
         // single-lane fix-ups, all decided on the scalar unit
-        if (pl.nvalid < 64) { set_in_lanes(ia, lanes_from(pl.nvalid), kItNop); set_in_lanes(ib, lanes_from(pl.nvalid), kItNop); }
+        if (pl.nvalid < 64) { set_in_lanes(ia, lanes_from(pl.nvalid), kItPadValue); set_in_lanes(ib, lanes_from(pl.nvalid), kItPadValue); }
         uint32_t va = (uint32_t)(int)(short)(ia & 0xFFFFu);
         const int vb = (int)(short)(ib & 0xFFFFu);
-        if (pl.f0) add_in_lanes(va, 1ull, 0u - pl.d0);                // first block of a tile: DC difference against the tile before (rle.c:68-70)
-        if (pl.l1 < 64) add_in_lanes(va, 1ull << pl.l1, 0u - pl.d1);
-        if (pl.l2 < 64) add_in_lanes(va, 1ull << pl.l2, 0u - pl.d2);
+        if (pl.f0) add_in_lanes(va, 1ull, (uint32_t)-pl.d0);          // first block of a tile: DC difference against the tile before (rle.c:68-70)
+        if (pl.l1 < 64) {
+            add_in_lanes(va, 1ull << pl.l1, (uint32_t)-pl.d1);
+            if (pl.l2 < 64) add_in_lanes(va, 1ull << pl.l2, (uint32_t)-pl.d2);
+        }
         const uint32_t pb = (uint32_t)lane_shift_up1((int)ib);
         const uint32_t prev_a = lane == 0 ? prev_b : pb;
         prev_b = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
@@ -230,8 +247,8 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         uint32_t zl = 0, zc = 0;
         if (__builtin_expect(any_zrl, 0)) {
             const uint32_t zw = s_huff[0xF0];
-            zc = zw & 0xFFFFu;
-            zl = zw >> 16;
+            zc = zw & ~31u;                                       // left-aligned
+            zl = zw & 31u;
             la += sa.zrl * zl;
             lb += sb.zrl * zl;
             nzrl += sa.zrl + sb.zrl;
@@ -243,7 +260,6 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         // younger store to be acknowledged): the window is written out only when the next batch might not fit.
         if (__builtin_expect(((carry_bits + batch_bits) >> 5) - wbase + 3u > (uint32_t)kSegBufWords, 0)) {
             const uint32_t done = (carry_bits >> 5) - wbase;            // complete words in the window
-            uint32_t *segw = a.seg.words + (size_t)seg * kSegCapWords;
             if (done) {
                 census(done - 1u, flushed);                              // the last complete word waits for its successor
                 const uint32_t part = win[done];
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
             const auto with_zrl = [&](const Sym &s, uint32_t &hi, uint32_t &lo) {
                 unsigned long long a64 = (unsigned long long)s.bits << 32;
                 for (uint32_t q = 0; q < 3; ++q)
-                    if (q < s.zrl) a64 = (a64 >> zl) | ((unsigned long long)zc << (64u - zl));
+                    if (q < s.zrl) a64 = (a64 >> zl) | ((unsigned long long)zc << 32);
                 hi = (uint32_t)(a64 >> 32);
                 lo = (uint32_t)a64;
             };
@@ -285,7 +301,6 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         const uint32_t done = (carry_bits >> 5) - wbase;
         const uint32_t nw = done + ((carry_bits & 31u) ? 1u : 0u);           // words holding bits; the window is zero behind them
         census(nw, flushed);
-        uint32_t *segw = a.seg.words + (size_t)seg * kSegCapWords;
         for (uint32_t j = (uint32_t)lane; j < nw; j += 64) segw[wbase + j] = win[j];
         if (!flushed) first_word = win[0];
         if (done) last_word = win[done - 1];

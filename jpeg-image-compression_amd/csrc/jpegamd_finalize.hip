@@ -47,8 +47,10 @@ __device__ __forceinline__ uint32_t fin_tail_bits(const FinalizeArgs &a, int s, 
 // plus the byte that straddles its start -- 0xFF iff the last p bits in front of it and its first 8 - p bits are all ones.
 // edge = (first 8 bits << 8) | last 7 bits of a segment's own string.  A segment shorter than 8 bits is "00 1010" (one
 // flat block): it has no leading one, and its tail ends in 0, so neither side can complete an 0xFF across it.
-__device__ __forceinline__ uint32_t fin_owned_ff(const FinalizeArgs &a, int t, uint32_t p, uint32_t edge_t, uint32_t edge_prev) {
-    uint32_t c = a.seg.ffin[(size_t)t * 8 + p];
+__device__ __forceinline__ uint32_t fin_owned_ff(uint4 ffin /*the segment's 8 counts, 16 bits each*/, int t, uint32_t p, uint32_t edge_t, uint32_t edge_prev) {
+    const uint32_t lo = (p & 4u) ? ffin.z : ffin.x, hi = (p & 4u) ? ffin.w : ffin.y;
+    const uint32_t w = (p & 2u) ? hi : lo;
+    uint32_t c = (p & 1u) ? w >> 16 : w & 0xFFFFu;
     if (p && t > 0) {
         const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(edge_prev & 0x7Fu));             // 0..7
         const uint32_t lead_ones = (uint32_t)__clz(~((edge_t >> 8) << 24));                    // 0..8
@@ -67,7 +69,7 @@ __device__ __forceinline__ uint32_t fin_ff_mask(uint32_t w) {
 
 __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs a) {
     __shared__ uint32_t s_wbits[kFinWaves], s_wff[kFinWaves];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), tid = (int)threadIdx.x;
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tid = (int)threadIdx.x;
     const int g = (int)blockIdx.x;
     const int s = g * kFinWaves + wave;
     const bool have = s < a.num_segs;
@@ -76,6 +78,17 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
         for (int i = tid; i < a.prefix_len; i += 64 * kFinWaves)
             if ((uint64_t)i < a.out_capacity) a.out[i] = a.prefix[i];
 
+    // Every load whose address does not depend on data is issued up front (this kernel is one chain of dependent round trips
+    // otherwise): the chunk's own per-segment numbers, and below the predecessors' -- all 8 phase counts of a segment are
+    // fetched (16 bytes) and the right one picked in registers once the phase is known.
+    const int sp = g * kFinWaves + (lane & 15);
+    const bool in = lane < kFinWaves && sp < a.num_segs;
+    const uint32_t vb = in ? a.seg.bits[sp] : 0u;
+    const uint32_t ve = in ? a.seg.edge[sp] : 0u;
+    const uint32_t ve_prev = (in && sp > 0) ? a.seg.edge[sp - 1] : 0u;
+    const uint4 vffin = in ? *reinterpret_cast<const uint4 *>(a.seg.ffin + (size_t)sp * 8) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t pbits = (have && s > 0) ? a.seg.bits[s - 1] : 0u;
+
     // ---- 1. everything in front of this chunk: bits (64-bit) and owned 0xFF bytes of the segments [0, 16 g) -------------
     // Thread tid takes four consecutive segments per round of 4096; a block-wide exclusive scan of the bit counts gives
     // each of them its byte phase (the sum is needed mod 8 only, so 32-bit wrap-around is harmless).
@@ -83,12 +96,14 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     unsigned long long chunk_b0 = 0, chunk_ff0 = 0;
     for (int base = 0; base < n_before; base += 4 * 64 * kFinWaves) {
         const int i = base + 4 * tid;
-        uint4 b = make_uint4(0u, 0u, 0u, 0u), e = make_uint4(0u, 0u, 0u, 0u);
+        uint4 b = make_uint4(0u, 0u, 0u, 0u), e = make_uint4(0u, 0u, 0u, 0u), f0 = b, f1 = b, f2 = b, f3 = b;
         uint32_t eprev = 0;
         if (i < n_before) {                                      // n_before is a multiple of 16: the four are all in front or none
             b = *reinterpret_cast<const uint4 *>(a.seg.bits + i);
             e = *reinterpret_cast<const uint4 *>(a.seg.edge + i);
             if (i > 0) eprev = a.seg.edge[i - 1];
+            const uint4 *fp = reinterpret_cast<const uint4 *>(a.seg.ffin + (size_t)i * 8);
+            f0 = fp[0]; f1 = fp[1]; f2 = fp[2]; f3 = fp[3];
         }
         const uint32_t tot = b.x + b.y + b.z + b.w;
         const uint32_t incl = wave_incl_scan_u32(tot);
@@ -100,8 +115,8 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
         const uint32_t x0 = (uint32_t)chunk_b0 + woff + incl - tot;                 // bit offset of segment i, mod 2^32
         uint32_t ff = 0;
         if (i < n_before) {
-            ff = fin_owned_ff(a, i, x0 & 7u, e.x, eprev) + fin_owned_ff(a, i + 1, (x0 + b.x) & 7u, e.y, e.x) +
-                 fin_owned_ff(a, i + 2, (x0 + b.x + b.y) & 7u, e.z, e.y) + fin_owned_ff(a, i + 3, (x0 + b.x + b.y + b.z) & 7u, e.w, e.z);
+            ff = fin_owned_ff(f0, i, x0 & 7u, e.x, eprev) + fin_owned_ff(f1, i + 1, (x0 + b.x) & 7u, e.y, e.x) +
+                 fin_owned_ff(f2, i + 2, (x0 + b.x + b.y) & 7u, e.z, e.y) + fin_owned_ff(f3, i + 3, (x0 + b.x + b.y + b.z) & 7u, e.w, e.z);
         }
         const uint32_t wff = (uint32_t)wave_sum_i32((int)ff);
         if (lane == 0) s_wff[wave] = wff;
@@ -116,14 +131,9 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     if (!have) return;                                            // no workgroup-wide synchronisation below
 
     // ---- 2. inside the chunk: lanes 0..15 of every wave hold the chunk's 16 segments ---------------------------------------
-    const int sp = g * kFinWaves + (lane & 15);
-    const bool in = lane < kFinWaves && sp < a.num_segs;
-    const uint32_t vb = in ? a.seg.bits[sp] : 0u;
-    const uint32_t ve = in ? a.seg.edge[sp] : 0u;
-    const uint32_t ve_prev = (in && sp > 0) ? a.seg.edge[sp - 1] : 0u;
     const uint32_t ib = wave_incl_scan_u32(vb);
     const uint32_t off_in = ib - vb;                                                // bits of the chunk in front of segment sp
-    const uint32_t vf = in ? fin_owned_ff(a, sp, ((uint32_t)chunk_b0 + off_in) & 7u, ve, ve_prev) : 0u;
+    const uint32_t vf = in ? fin_owned_ff(vffin, sp, ((uint32_t)chunk_b0 + off_in) & 7u, ve, ve_prev) : 0u;
     const uint32_t iff = wave_incl_scan_u32(vf);
     const uint32_t my_bits = (uint32_t)__builtin_amdgcn_readlane((int)vb, wave);
     const uint32_t my_ff = (uint32_t)__builtin_amdgcn_readlane((int)vf, wave);
@@ -137,7 +147,6 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     const uint32_t lead = (uint32_t)(b0 & 7u);
     uint32_t leadbits = 0;                                                          // the `lead` bits in front of the segment
     if (lead && s > 0) {
-        const uint32_t pbits = a.seg.bits[s - 1];
         leadbits = pbits >= 7u ? (prev_edge & ((1u << lead) - 1u)) : fin_tail_bits(a, s, (int)lead);
     }
 

@@ -23,12 +23,18 @@ constexpr int kSegCapWords = ((kSegBlocks * kMaxBlockBits + 31) / 32 + 1 + 63) /
 constexpr int kAFragWords = 3 * 2 * 4 * 64 * 4;                      // [term][chain][kstep][lane] x 8 bf16 = 24 KiB
 
 // Per-tile symbol lists in HBM (k_tile_transform -> k_entropy).  A list holds the tile's items from word 0, in block order
-// then zigzag order; a block's run is: DC item, non-zero AC items, EOB item (position 64) unless zigzag 63 is non-zero.
-// The count is padded to an EVEN number with one kItNop item, so that k_entropy's lanes (two items each) never straddle
+// then zigzag order; a block's run is: DC item, non-zero AC items, EOB item (kItEobValue) unless zigzag 63 is non-zero.
+// The count is padded to an EVEN number with one padding item (kItPadValue), so that k_entropy's lanes (two items each) never straddle
 // two lists.  The list's last 4 words are the tile record {items (unpadded), DC of the last block, exact-path count, 0}.
 constexpr uint32_t kItDc = 0x80000000u;         // item is a DC difference
 constexpr uint32_t kItFirst = 0x40000000u;      // ... of the first block of its tile: the value is the ABSOLUTE DC
-constexpr uint32_t kItNop = 0x20000000u;        // padding item: codes nothing
+constexpr uint32_t kItNop = 0x20000000u;        // marks the padding item
+// The padding item: a DC-flagged item of size 12 -- a size the Huffman table has no code for -- whose amplitude bits are all
+// zero (value -4095: amplitude code -4096 = ...1 0000 0000 0000).  k_entropy codes it like any other item; it yields no bit.
+constexpr uint32_t kItPadValue = kItNop | kItDc | 0xF001u;
+// The EOB item (rle.c:121-123) in the same style: DC-flagged, size 13, amplitude bits all zero (value -8191); k_entropy's table
+// holds the EOB code under "DC size 13".  A non-DC item is therefore always a non-zero AC coefficient.
+constexpr uint32_t kItEobValue = kItDc | 0xE001u;
 constexpr int kTileItemCap = (kTileBlocks * 65 + 64 + 4 + 63) / 64 * 64;   // 2176 words
 constexpr int kTileRecord = kTileItemCap - 4;
 static_assert(kTileBlocks * 65 + 64 <= kTileRecord, "the per-tile record must lie behind the longest list and its read-ahead");

@@ -459,11 +459,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
             }
             if (eob) {
                 if (!gact[3]) off = (blk_base + (starts >> 24)) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b32(64u << 16, lrsrc, off, 0, JPEGAMD_ITEM_AUX);     // value 0, not DC = EOB
+                __builtin_amdgcn_raw_buffer_store_b32(kItEobValue, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
             }
         }
         if (lane == 0) {
-            if (t_all & 1u) list[t_all] = kItNop;                   // k_entropy's lanes take two items each: even count per list
+            if (t_all & 1u) list[t_all] = kItPadValue;                   // k_entropy's lanes take two items each: even count per list
             *reinterpret_cast<uint4 *>(list + kTileRecord) =
                 make_uint4(t_all, (uint32_t)__builtin_amdgcn_readlane(n[0], nblk - 1), (uint32_t)nexact, 0u);
         }
