@@ -20,7 +20,8 @@ constexpr int kSegBlocks = kTileBlocks * kSegTiles;                  // 256
 // Worst case bits per block: DC 9+11, 63 x (16+11) AC (quality 100 -> 11-bit amplitudes).
 constexpr int kMaxBlockBits = 20 + 63 * 27;                          // 1721
 constexpr int kSegCapWords = ((kSegBlocks * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64;   // words reserved per segment
-constexpr int kAFragWords = 3 * 2 * 4 * 64 * 4;                      // [term][chain][kstep][lane] x 8 bf16 = 24 KiB
+constexpr int kAFragWords = 2 * 2 * 4 * 64 * 4;                      // [term][chain][kstep][lane] x 8 binary16 = 16 KiB
+constexpr float kMfmaScale = 16384.0f;                               // the A fragments hold kMfmaScale * LUT product
 
 // Per-tile symbol lists in HBM (k_tile_transform -> k_entropy).  A list holds the tile's items from word 0, in block order
 // then zigzag order; a block's run is: DC item, non-zero AC items, EOB item (kItEobValue) unless zigzag 63 is non-zero.
@@ -40,13 +41,13 @@ constexpr int kTileRecord = kTileItemCap - 4;
 static_assert(kTileBlocks * 65 + 64 <= kTileRecord, "the per-tile record must lie behind the longest list and its read-ahead");
 
 struct MfmaTables {
-    uint32_t afrag[kAFragWords];   // LUT-product matrix, 3-way bf16 split (lo, mid, hi), MFMA A-operand order
-    float qmul[64];                // by zigzag position z: M_z = K/(q)  (the MFMA output is the plain LUT sum)
+    uint32_t afrag[kAFragWords];   // kMfmaScale * LUT-product matrix, 2-way binary16 split (lo, hi), MFMA A-operand order
+    float qmul[64];                // by zigzag position z: M_z = K / (q * kMfmaScale)  (the MFMA output is kMfmaScale * LUT sum)
     float qthr[64];                // (bias - 0.5) + delta_z
     float qstep[64];               // (float) q, by zigzag position
     float bias;                    // 0.5 + max_z delta_z
     float pad[3];
-    float grp_thr[8];              // [group G][lane half h]: |LUT sum| below it => zigzag 16G+8h .. +7 all quantise to an unflagged 0
+    float grp_thr[8];              // [group G][lane half h]: |MFMA output| below it => zigzag 16G+8h .. +7 all quantise to an unflagged 0
 };
 
 struct ScanStats {                   // device-side per-call record

@@ -21,7 +21,7 @@
 
 namespace jpegamd {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #ifndef JPEGAMD_AFR_BATCH
@@ -45,29 +45,50 @@ __device__ __forceinline__ RawRow load_raw_row(const uint32_t *__restrict__ src)
     return r;
 }
 
-__device__ __forceinline__ bf16x8 luma_row8_bf16(const RawRow &raw, uint32_t w) {
-    const uint32_t d0 = raw.d[0], d1 = raw.d[1], d2 = raw.d[2], d3 = raw.d[3], d4 = raw.d[4], d5 = raw.d[5];
+// Luma weights as the six dot-product operands of a pixel row (3 bytes per pixel: a pixel starts at byte 0, 3, 2 or 1 of a dword).
+struct LumaWeights { uint32_t a, b0, b1, c0, c1, d; };
+__device__ __forceinline__ LumaWeights luma_weights(uint32_t w /*weights of stored bytes 0, 1, 2*/) {
     const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu;
-    const uint32_t wA = w, wB0 = c0 << 24, wB1 = c1 | (c2 << 8), wC0 = (c0 << 16) | (c1 << 24), wC1 = c2, wD = w << 8;
-    const uint32_t kC = 0xFFFF8000u;
-    // the centred luma is the signed byte at bits 8..15 of (sum - 32768): written as a byte extraction so that the
-    // conversion can take it straight from the dot product's register (SDWA byte select) without a separate shift
-    uint32_t sdot[8];
-    sdot[0] = __builtin_amdgcn_udot4(d0, wA, kC, false);
-    sdot[1] = __builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, kC, false), false);
-    sdot[2] = __builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, kC, false), false);
-    sdot[3] = __builtin_amdgcn_udot4(d2, wD, kC, false);
-    sdot[4] = __builtin_amdgcn_udot4(d3, wA, kC, false);
-    sdot[5] = __builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, kC, false), false);
-    sdot[6] = __builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, kC, false), false);
-    sdot[7] = __builtin_amdgcn_udot4(d5, wD, kC, false);
-    int y[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = (int)(int8_t)(sdot[j] >> 8);
-    bf16x8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (__bf16)(float)y[j];      // |y| <= 128: exact in bf16
-    return r;
+    LumaWeights l;
+    l.a = w; l.b0 = c0 << 24; l.b1 = c1 | (c2 << 8); l.c0 = (c0 << 16) | (c1 << 24); l.c1 = c2; l.d = w << 8;
+    return l;
+}
+
+// 8 pixels (24 bytes) -> 8 centred luma values (converter.c:51,84-86) as binary16, the B fragment of one k-step half.
+// Y = (w . rgb) >> 8 is byte 1 of the dot product; with 0xFFFF8000 (= -32768) as the accumulator input that byte IS the
+// centred value as a signed byte, and one v_cvt_f16_i16 with an SDWA byte select converts it straight into its half of
+// the packed register: 12 v_dot4 + 8 converts per 8 pixels (round 1: + 6 packs to bf16 + 4 permutes).  One asm block, so
+// that every convert reads a dot product issued at least three instructions earlier (DOT -> SDWA read hazard on gfx950,
+// which hipcc pads for its own instructions only).
+__device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeights &w, uint32_t kc) {
+    uint32_t o0, o1, o2, o3, t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_dot4_u32_u8 %[t0], %[d0], %[wa], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t1], %[d0], %[wb0], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t2], %[d1], %[wc0], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t3], %[d2], %[wd], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t4], %[d3], %[wa], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t5], %[d3], %[wb0], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t6], %[d4], %[wc0], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t7], %[d5], %[wd], %[kc]\n\t"
+        "v_dot4_u32_u8 %[t1], %[d1], %[wb1], %[t1]\n\t"
+        "v_dot4_u32_u8 %[t2], %[d2], %[wc1], %[t2]\n\t"
+        "v_dot4_u32_u8 %[t5], %[d4], %[wb1], %[t5]\n\t"
+        "v_dot4_u32_u8 %[t6], %[d5], %[wc1], %[t6]\n\t"
+        "v_cvt_f16_i16_sdwa %[o0], sext(%[t0]) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
+        "v_cvt_f16_i16_sdwa %[o1], sext(%[t3]) dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
+        "v_cvt_f16_i16_sdwa %[o2], sext(%[t4]) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
+        "v_cvt_f16_i16_sdwa %[o3], sext(%[t7]) dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
+        "v_cvt_f16_i16_sdwa %[o0], sext(%[t1]) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n\t"
+        "v_cvt_f16_i16_sdwa %[o1], sext(%[t2]) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n\t"
+        "v_cvt_f16_i16_sdwa %[o2], sext(%[t5]) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n\t"
+        "v_cvt_f16_i16_sdwa %[o3], sext(%[t6]) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1"
+        : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+          [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
+        : [d0] "v"(raw.d[0]), [d1] "v"(raw.d[1]), [d2] "v"(raw.d[2]), [d3] "v"(raw.d[3]), [d4] "v"(raw.d[4]), [d5] "v"(raw.d[5]),
+          [wa] "s"(w.a), [wb0] "s"(w.b0), [wb1] "s"(w.b1), [wc0] "s"(w.c0), [wc1] "s"(w.c1), [wd] "s"(w.d), [kc] "v"(kc));
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    const u32x4 packed = {o0, o1, o2, o3};
+    return __builtin_bit_cast(f16x8, packed);
 }
 
 
@@ -122,7 +143,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     __shared__ float s_cos[64];
     __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][64];   // exact-order path: the 64 terms of one coefficient
     __shared__ float s_grp[8];                 // [group][h]: |acc| below this => every site of the group quantises to an unflagged 0
-    // The tile's centred luma (bf16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
+    // The tile's centred luma (binary16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
     // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
     // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
     // prefetched rows of the NEXT tile as well: ~40 % of a tile's time per event (tools/stamp_profile_tile.py).
@@ -150,6 +171,8 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
     const int h = lane >> 5, b = lane & 31;
     const float bias = out.tables->bias;
+    const LumaWeights lw = luma_weights(im.weights);
+    const uint32_t luma_kc = 0xFFFF8000u;
     const float2 *sq_lane = &s_q[8 * h];
 
     // Persistent waves: tile = first, first + stride, ...  The matrix image is loaded once per workgroup and the
@@ -239,22 +262,22 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         int nexact = 0;
         TSTAMP(0);   // loop overhead / geometry
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
-        bf16x8 bfrag[4];
+        f16x8 bfrag[4];
         if (interior) {
             request_rows(tg, raw);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_bf16(raw[s], im.weights);
+            for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_f16(raw[s], lw, luma_kc);
         } else {
             // edge tile (right/bottom replication, converter.c:31,36) or unaligned source: clamped byte gather
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    bfrag[s][j] = (__bf16)(float)(luma_clamped(im, px0 + j, py0 + 2 * s + h) - 128);
+                    bfrag[s][j] = (_Float16)(float)(luma_clamped(im, px0 + j, py0 + 2 * s + h) - 128);
         }
         TSTAMP(1);   // wait for the prefetched rows + luma
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x8 *>(&s_pix[wave][(2 * s + h) * 132 + b * 4]) = bfrag[s];
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&s_pix[wave][(2 * s + h) * 132 + b * 4]) = bfrag[s];
         TSTAMP(2);   // issue of the next tile's loads
         if (kTaps && active && out.tap_y) {
             int8_t *ty = out.tap_y + ((size_t)by * im.blocks_w + bx) * 64;
@@ -267,16 +290,16 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // ---- 2. the 64x64 transform on the matrix pipe: small terms first ----------------------
         f32x16 acc[2];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {          // unrolled (a rolled loop paid ~12 scalar/branch slots per term for the C = 0 special case);
+        for (int t = 0; t < 2; ++t) {          // unrolled (a rolled loop paid ~12 scalar/branch slots per term for the C = 0 special case);
                                                // the A fragments of one term are fetched kAfrBatch at a time so that
             const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];     // the MFMAs issue back to back behind ONE wait
 #pragma unroll
             for (int s0 = 0; s0 < 4; s0 += kAfrBatch) {
-                bf16x8 afr[2][kAfrBatch];
+                f16x8 afr[2][kAfrBatch];
 #pragma unroll
                 for (int H = 0; H < 2; ++H)
 #pragma unroll
-                    for (int i = 0; i < kAfrBatch; ++i) afr[H][i] = *reinterpret_cast<const bf16x8 *>(&at[((H * 4 + s0 + i) * 64) * 4]);
+                    for (int i = 0; i < kAfrBatch; ++i) afr[H][i] = *reinterpret_cast<const f16x8 *>(&at[((H * 4 + s0 + i) * 64) * 4]);
                 __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMAs (hipcc otherwise sinks each read next to its use)
 #pragma unroll
                 for (int i = 0; i < kAfrBatch; ++i)
@@ -284,9 +307,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     for (int H = 0; H < 2; ++H) {
                         if (t == 0 && s0 + i == 0) {       // C = 0 as an inline constant: no accumulator clearing
                             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[H][i], bfrag[0], zero, 0, 0, 0);
+                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[0], zero, 0, 0, 0);
                         } else {
-                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[H][i], bfrag[s0 + i], acc[H], 0, 0, 0);
+                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[s0 + i], acc[H], 0, 0, 0);
                         }
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -337,7 +360,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         {
             const bool dcflag = (h == 0) && (flagbits & 1u);
             if (__ballot(dcflag) != 0ull) {
-                const int dc_exact = ref_quantise(__fmul_rn(ref_scale(0, 0), acc[0][0]), s_qstep[0]);
+                const int dc_exact = ref_quantise(__fmul_rn(ref_scale(0, 0), __fmul_rn(acc[0][0], 1.0f / kMfmaScale)), s_qstep[0]);   // the scaled sum is exact, and so is 2^-14 of it
                 if (dcflag) n[0] = dc_exact;
             }
             if (h == 0) flagbits &= ~1u;
@@ -364,7 +387,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     const int z = 16 * (st >> 3) + 8 * (fl >> 5) + (st & 7);
                     const int k = kZZ[z], u = k >> 3, v = k & 7;
                     const uint32_t pw = s_pix[wave][(lane >> 3) * 132 + (fl & 31) * 4 + ((lane & 7) >> 1)];
-                    const float pix = __builtin_bit_cast(float, (lane & 1) ? (pw & 0xFFFF0000u) : (pw << 16));   // bf16 -> f32
+                    const float pix = (float)__builtin_bit_cast(_Float16, (uint16_t)((lane & 1) ? pw >> 16 : pw));
                     const float coef = exact_coef_float_lds(pix, u, v, s_cos, s_terms[wave], lane);
                     const int val = ref_quantise(coef, s_qstep[z]);
                     ++nexact;

@@ -118,27 +118,36 @@ constexpr double kPmax = 128.0;
 }  // namespace
 
 // ---- matrix-pipe tables ----------------------------------------------------------------------
-// out_z = sum_p Kmat[c][p] * pix[p], Kmat[c][p] = COS_LUT[x][u] * COS_LUT[y][v] (exact product of the two
-// float32 literals), computed by 12 v_mfma_f32_32x32x16_bf16 per chain: Kmat = lo + mid + hi in bf16,
-// pixels (int8) exact in bf16, so every product is exact in f32 and only accumulation rounds.
-// Guard band: E_lut vanishes (the fast path evaluates the LUT sum itself); E_aan is replaced by
-//   E_mfma = 2 * 16u * sum_m (|acc before MFMA m| + S_m),   S_m = 128 * sum_{p in k-step m} |term|
-// which holds for ANY order in which the hardware adds the 16 products of one instruction to the
-// accumulator (the factor 2 covers truncating adders); plus the split residual 128*sum|Kmat - (lo+mid+hi)|.
-// tools/ubench/mfma_dct_test.hip measured the real error at < 1 % of this bound.
+// out_z = sum_p Kmat[c][p] * pix[p], Kmat[c][p] = COS_LUT[x][u] * COS_LUT[y][v] (exact product of the two float32
+// literals), computed by 8 v_mfma_f32_32x32x16_f16 per chain: kMfmaScale * Kmat = hi + lo in binary16 (22 significant
+// bits; the scale 2^14 keeps lo out of the subnormal range), pixels (int8) exact in binary16, so every product is exact
+// in f32 and only accumulation rounds.  Round 1 used three bf16 terms (24 bits, 12 MFMAs per chain): the third term bought
+// a residual of 2^-25 |K| where 2^-23 |K| is still < 10 % of the reference's own evaluation error E_ref.
+// Guard band: E_mfma = 2 * 16u * sum_m (|acc before MFMA m| + S_m),   S_m = 128 * sum_{p in k-step m} |term|
+// holds for ANY order in which the hardware adds the 16 products of one instruction to the accumulator (the factor 2
+// covers truncating adders); plus the split residual 128*sum|Kmat - (hi+lo)/scale|, taken as the larger of "lo kept" and
+// "lo flushed to zero where it is a binary16 subnormal" (never the case at this scale unless the residual is ~0 anyway).
 namespace {
-uint16_t to_bf16(double x) {
-    float f = (float)x;
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// double -> IEEE binary16 bits, round to nearest even, subnormals kept; |x| < 65520
+uint16_t to_f16(double x) {
+    const uint16_t sign = x < 0 ? 0x8000u : 0u;
+    double a = std::fabs(x);
+    if (a == 0.0) return sign;
+    int e;
+    (void)std::frexp(a, &e);                       // a = m * 2^e, 0.5 <= m < 1  ->  exponent of the leading bit: e - 1
+    int ex = e - 1;
+    if (ex < -14) ex = -14;                        // subnormal range: fixed quantum 2^-24
+    const double quantum = std::ldexp(1.0, ex - 10);
+    double n = std::nearbyint(a / quantum);        // default rounding mode: to nearest even
+    if (n >= 2048.0) { n *= 0.5; ++ex; }           // rounded up into the next binade
+    const uint32_t mant = (uint32_t)n;             // 1024..2047 normal, 0..1023 subnormal
+    if (mant < 1024u) return (uint16_t)(sign | mant);
+    return (uint16_t)(sign | ((uint32_t)(ex + 15) << 10) | (mant - 1024u));
 }
-double from_bf16(uint16_t b) {
-    uint32_t u = (uint32_t)b << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return (double)f;
+double from_f16(uint16_t b) {
+    const int ex = (b >> 10) & 31, mant = b & 1023;
+    const double v = ex ? std::ldexp((double)(1024 + mant), ex - 25) : std::ldexp((double)mant, -24);
+    return (b & 0x8000u) ? -v : v;
 }
 }  // namespace
 
@@ -147,37 +156,38 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
     uint16_t *af = reinterpret_cast<uint16_t *>(mt->afrag);
     double delta_z[64];
     double dmax = 0;
+    const double S = (double)kMfmaScale;
     for (int z = 0; z < 64; ++z) {
         const int k = kZigzagHost[z], u = k >> 3, v = k & 7;
-        double kmat[64], term[3][64], split_res = 0;
+        double kmat[64], term[2][64], split_res = 0;       // terms in units of Kmat (i.e. already divided by the scale)
         for (int x = 0; x < 8; ++x)
             for (int y = 0; y < 8; ++y) {
                 const int p = x * 8 + y;
                 kmat[p] = (double)kCosLut[x][u] * (double)kCosLut[y][v];
-                const uint16_t hi = to_bf16(kmat[p]);
-                const double r1 = kmat[p] - from_bf16(hi);
-                const uint16_t mid = to_bf16(r1);
-                const double r2 = r1 - from_bf16(mid);
-                const uint16_t lo = to_bf16(r2);
-                term[0][p] = from_bf16(lo); term[1][p] = from_bf16(mid); term[2][p] = from_bf16(hi);
-                split_res += std::fabs(kmat[p] - (term[0][p] + term[1][p] + term[2][p]));
-                // scatter into the A-operand order: chain H, matrix row R, k-step s, lane (hk, R), element j;
+                const uint16_t hi = to_f16(kmat[p] * S);
+                const double r1 = kmat[p] * S - from_f16(hi);
+                const uint16_t lo = to_f16(r1);
+                term[0][p] = from_f16(lo) / S; term[1][p] = from_f16(hi) / S;
+                const double res_kept = std::fabs(kmat[p] - (term[0][p] + term[1][p]));
+                const double res_flushed = ((lo & 0x7C00u) == 0) ? std::fabs(kmat[p] - term[1][p]) : res_kept;
+                split_res += std::fmax(res_kept, res_flushed);
+                // scatter into the A-operand order: term t, chain H, matrix row R, k-step s, lane (hk, R), element j;
                 // lane half h = (z >> 3) & 1 holds z = 16G + 8h + j at site 8G + j = 16H + r
                 const int site = 8 * (z >> 4) + (z & 7);
                 const int h = (z >> 3) & 1, H = site >> 4, r = site & 15;
                 const int R = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int s = p >> 4, hk = (p >> 3) & 1, j = p & 7;
                 const int lane = 32 * hk + R;
-                const uint16_t t3[3] = {lo, mid, hi};
-                for (int t = 0; t < 3; ++t) af[((((size_t)t * 2 + H) * 4 + s) * 64 + lane) * 8 + j] = t3[t];
+                const uint16_t t2[2] = {lo, hi};
+                for (int t = 0; t < 2; ++t) af[((((size_t)t * 2 + H) * 4 + s) * 64 + lane) * 8 + j] = t2[t];
             }
         // reference evaluation error: two roundings per product, 63 sequential float32 additions (dct.c:84)
         double wsum = 0, run = 0, adds = 0;
         for (int j = 0; j < 64; ++j) { const double w = std::fabs(kmat[j]); wsum += w; run += w; if (j >= 1) adds += run; }
         const double e_ref = (2.0 * kU * kPmax * wsum + kU * kPmax * adds) * 1.001;
-        // accumulation bound, MFMA order: terms lo, mid, hi; k-steps 0..3 inside each
+        // accumulation bound, MFMA order: terms lo, hi; k-steps 0..3 inside each (in Kmat units: the scale cancels)
         double acc = 0, e_mfma = 0;
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 2; ++t)
             for (int s = 0; s < 4; ++s) {
                 double sm = 0;
                 for (int j = 0; j < 16; ++j) sm += std::fabs(term[t][16 * s + j]) * kPmax;
@@ -191,7 +201,7 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
         const double delta = (K / q) * (e_ref + e_mfma + kPmax * split_res) + 4.0 * kU * (zmax + 1.0);
         delta_z[z] = delta;
         if (z > 0 && delta > dmax) dmax = delta;
-        mt->qmul[z] = (float)(K / q);
+        mt->qmul[z] = (float)(K / (q * S));                 // the accumulator holds kMfmaScale * LUT sum
         mt->qstep[z] = (float)table[k];
         if (delta_out) delta_out[k] = delta;
     }
