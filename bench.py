@@ -5,21 +5,31 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU.
 Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[2], the config the roofline target is quoted on): one
-8192x8192 synthetic 24-bit BMP per rank per step, reference quantisation table (Q=50),
-pixel rows already resident in HBM; output = complete JFIF file bytes in HBM.  A "step" is
-one pass of the hot path (k_tile_transform -> k_entropy -> k_fin_count2 -> k_fin_write2) over one
-image.  Inputs rotate over 3 distinct images per rank (603 MB > the 256 MiB Infinity Cache).  Steps
-alternate over `--streams` encoder contexts / HIP streams (default 4) so the tail kernels of one
-image overlap the transform of the next; every step is still one complete encode.  With N > 1 every
-rank encodes its own images (weak scaling, no data-path collective inside the encode) and the
-finished bitstreams are collected at rank 0 with one asynchronous RCCL gather per `--gather-every`
-images (jpegamd.sharding.BatchedStreamGather), overlapped with the following steps.
+Workloads (`--workload`, default `auto`):
+  image8192  BASELINE.json configs[2], the config the metric and the roofline target are quoted on: one 8192x8192
+             synthetic 24-bit BMP per rank per step, 3 rotating inputs per rank (603 MB > the 256 MiB Infinity Cache).
+             This is what `auto` selects at EVERY N: the driver derives the scaling efficiency from the per-N values, so
+             the per-rank work has to be the same at N = 1 and N = 8 (weak scaling).
+  batch4096  BASELINE.json configs[3]: independent 4096x4096 images, 8 per rank per step (N = 8: the batch of 64),
+             distinct seeds (tests/golden/batch4096.json holds the compiled reference's answers for all 64), every
+             finished bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
+Reference quantisation table (Q=50) unless --quality says otherwise; pixel rows resident in HBM; output = complete
+JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_transform -> k_entropy -> k_finalize) over the
+step's images.  Steps alternate over `--streams` encoder contexts / HIP streams (default 4) so the latency-bound tail
+kernels of one image overlap the transform of the next; every step is still a complete encode.  With N > 1 every rank
+encodes its own images (weak scaling, no data-path collective inside the encode) and the finished bitstreams are
+collected at rank 0 with one asynchronous RCCL gather per `--gather-every` images
+(jpegamd.sharding.BatchedStreamGather), overlapped with the following steps.
 
-Extra objects on the JSON line: "roofline" (dominant kernel = k_tile_transform, HIP-event timed
-inside this run through the C-ABI's event ring; with several streams the durations come from a
-single-stream pass right after the timed region) and "cpu_baseline" (the compiled reference
-natural_c, single thread, on a bounded sample; rank 0, N == 1 only).
+Extra objects on the JSON line:
+  "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes (BMP rows read + JFIF bytes
+                  written, per image) / SUM of the kernels' durations / 8 TB/s.  Durations are HIP-event timed inside
+                  this run through the C-ABI's event ring, on the stream the kernels are launched on; with several
+                  streams they come from a single-stream pass right after the timed region (kernels of different images
+                  overlap in the timed region).  `dominant_frac` is the same bytes over k_tile_transform alone,
+                  `hbm_read_frac` the read bytes alone over the sum.
+  "cpu_baseline"  the compiled reference natural_c (oracle/_ref), single thread, on a bounded sample: with its own
+                  flags (no -O) and with -O2; rank 0, N == 1 only.
 """
 from __future__ import annotations
 
@@ -37,7 +47,8 @@ sys.path.insert(0, str(ROOT / "jpeg-image-compression_amd" / "python"))
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-ROTATE = 3
+ROTATE = 3                     # image8192: rotating inputs per rank
+BATCH_PER_RANK = 8             # batch4096: images per rank per step
 
 
 def parse_args():
@@ -45,31 +56,30 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--width", type=int, default=8192)
-    ap.add_argument("--height", type=int, default=8192)
+    ap.add_argument("--workload", choices=["auto", "image8192", "batch4096"], default="auto")
+    ap.add_argument("--width", type=int, default=0, help="override the workload's image width")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--kind", type=int, default=0, help="synthetic content: 0 photo-like, 1 noise, 2 flat, 3 gradient")
     ap.add_argument("--quality", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams (one encoder context each) the steps alternate over; >1 lets the latency-bound tail "
+                    help="HIP streams (one encoder context each) the images alternate over; >1 lets the latency-bound tail "
                          "kernels of one image overlap the transform kernel of the next")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 gather path with a one-rank group (rehearsal on one GPU)")
     ap.add_argument("--gather-every", type=int, default=32,
                     help="N > 1: images per rank carried by one gather to rank 0 (few, large collectives)")
-    ap.add_argument("--cpu-sample-rows", type=int, default=2048,
-                    help="rows of the step-0 image the CPU baseline encodes (bounded sample)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=8192,
+                    help="rows of the first image the CPU baseline encodes (bounded sample)")
     return ap.parse_args()
 
 
-def make_inputs(args, rank, torch, jpegamd):
-    """-> (list of device pixel tensors, stride, host bytes of image 0's BMP file)."""
-    w, h = args.width, args.height
+def make_inputs(args, rank, torch, jpegamd, w, h, seeds):
+    """-> (list of device pixel tensors, stride, host bytes of the first image's BMP file on rank 0)."""
     size = jpegamd.synth_bmp_into(0, 0, w, h)                     # query
     host = torch.empty(size, dtype=torch.uint8).pin_memory()
     stride = (3 * w + 3) & ~3
     dev, first = [], None
-    for i in range(ROTATE):
-        seed = 1000 + rank * ROTATE + i
+    for i, seed in enumerate(seeds):
         got = jpegamd.synth_bmp_into(host.data_ptr(), size, w, h, seed, args.kind, 0)
         assert got == size
         if i == 0 and rank == 0:
@@ -78,24 +88,35 @@ def make_inputs(args, rank, torch, jpegamd):
     return dev, stride, first
 
 
-def cpu_baseline(first_bmp: bytes, args):
-    """Time the reference's own code (oracle/_ref) on a bounded sample; fall back to the port."""
+def cpu_info():
+    model, cores = "unknown", os.cpu_count() or 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, cores
+
+
+def cpu_baseline(first_bmp: bytes, args, w, h):
+    """Time the reference's own code (oracle/_ref) on a bounded sample: its Makefile flags (no -O), and -O2."""
     import numpy as np
-    w, h = args.width, args.height
     rows = min(h, max(8, args.cpu_sample_rows // 8 * 8))
     stride = (3 * w + 3) & ~3
     px = np.frombuffer(first_bmp, np.uint8, offset=54).reshape(h, stride)
     top = px[h - rows:, :]                                        # bottom-up file: last `rows` stored rows = top of image
     from oracle import oracle
-    sample = f"top {rows} rows of the step-0 {w}x{h} image ({w * rows / 1e6:.1f} Mpx), single thread"
-    ref_lib = oracle.REF_LIB
-    if ref_lib.exists():
+    model, cores = cpu_info()
+    sample = f"top {rows} rows of the first {w}x{h} image ({w * rows / 1e6:.1f} Mpx), single thread"
+
+    class BMPImage(ctypes.Structure):
+        _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("data", ctypes.c_void_p)]
+
+    def time_ref(lib_path):
         rgb = np.ascontiguousarray(top[::-1, :3 * w].reshape(rows, w, 3)[:, :, ::-1])   # RGB top-down, tight
-        lib = ctypes.CDLL(str(ref_lib))
-
-        class BMPImage(ctypes.Structure):
-            _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("data", ctypes.c_void_p)]
-
+        lib = ctypes.CDLL(str(lib_path))
         lib.saveJPEGGrayscale.restype = ctypes.c_bool
         lib.saveJPEGGrayscale.argtypes = [ctypes.c_char_p, ctypes.POINTER(BMPImage)]
         img = BMPImage(w, rows, rgb.ctypes.data)
@@ -116,10 +137,21 @@ def cpu_baseline(first_bmp: bytes, args):
             os.unlink(out)
         except OSError:
             pass
-        if ok:
-            return {"value": round(w * rows / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
-                    "sample": sample + "; natural_c built with its own flags (-g, no -O), in-memory BMPImage in, "
-                                       "JPEG written to /dev/shm", "seconds": round(dt, 2)}
+        return dt if ok else None
+
+    base = {"unit": "Mpixels/s", "cores": 1, "cpu_model": model, "host_cores": cores}
+    if oracle.REF_LIB.exists():
+        dt = time_ref(oracle.REF_LIB)
+        if dt:
+            res = dict(base, value=round(w * rows / dt / 1e6, 3), kind="reference", seconds=round(dt, 2),
+                       sample=sample + "; natural_c built with its own flags (natural_c/Makefile:4: -g, no -O), in-memory "
+                                       "BMPImage in, JPEG written to /dev/shm")
+            if oracle.REF_LIB_O2.exists():
+                dt2 = time_ref(oracle.REF_LIB_O2)
+                if dt2:
+                    res["O2"] = {"value": round(w * rows / dt2 / 1e6, 3), "unit": "Mpixels/s", "seconds": round(dt2, 2),
+                                 "flags": "the same sources with -O2 added (identical bytes)"}
+            return res
     # port: this repo's restatement (-O2)
     hdr = bytearray(first_bmp[:54])
     hdr[22:26] = int(rows).to_bytes(4, "little", signed=True)
@@ -127,8 +159,8 @@ def cpu_baseline(first_bmp: bytes, args):
     t0 = time.perf_counter()
     oracle.encode_bmp(bmp, args.quality)
     dt = time.perf_counter() - t0
-    return {"value": round(w * rows / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": sample + "; oracle/natural_oracle.c at -O2", "seconds": round(dt, 2)}
+    return dict(base, value=round(w * rows / dt / 1e6, 3), kind="port", seconds=round(dt, 2),
+                sample=sample + "; oracle/natural_oracle.c at -O2")
 
 
 def main():
@@ -162,13 +194,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    w, h, K, W = args.width, args.height, args.steps, args.warmup
-    inputs, stride, first_bmp = make_inputs(args, rank, torch, jpegamd)
+    workload = args.workload if args.workload != "auto" else "image8192"
+    if workload == "image8192":
+        w, h, ips = args.width or 8192, args.height or 8192, 1
+        seeds = [1000 + rank * ROTATE + i for i in range(ROTATE)]
+    else:
+        w, h, ips = args.width or 4096, args.height or 4096, BATCH_PER_RANK
+        seeds = [2000 + rank * BATCH_PER_RANK + i for i in range(BATCH_PER_RANK)]
+    K, W = args.steps, args.warmup
+    inputs, stride, first_bmp = make_inputs(args, rank, torch, jpegamd, w, h, seeds)
+    nimg = len(inputs)
     nstreams = max(1, args.streams)
     encs = [jpegamd.Encoder(w, h) for _ in range(nstreams)]
-    enc = encs[0]
-    cap = 4096 + w * h // 2                                       # >10x the typical photo-like output
-    nbuf = 2 * nstreams
+    cap = 4096 + w * h // 2 if args.kind != 1 and args.quality <= 75 else 4096 + 2 * w * h     # >10x the typical photo-like output
+    nbuf = max(2 * nstreams, nimg)
     outs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(nbuf)]
     imgs = [jpegamd.Encoder.image(t.data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, args.quality) for t in inputs]
@@ -176,7 +215,7 @@ def main():
 
     # N > 1: the finished bitstreams are collected at rank 0, `gather_every` images per collective (few, large
     # messages: each peer's records cross its own xGMI link to the root in one piece).  The record size is fixed
-    # before the timed region from the sizes the rotating inputs actually produce (+5 %), agreed over all ranks.
+    # before the timed region from the sizes the inputs actually produce (+5 %), agreed over all ranks.
     gather = None
     G = max(1, args.gather_every)
     if dist is not None:
@@ -192,50 +231,62 @@ def main():
         rec_ptrs = {}
         for st_i in range(2 * G):
             pl, sz = gather.record(st_i)
-            rec_ptrs[st_i] = (pl.data_ptr(), pl.numel(), sz.data_ptr())
-    pending = [None] * nbuf
-    last_step = [-1]
+            rec_ptrs[st_i] = (pl.data_ptr(), pl.numel(), sz.data_ptr(), sz)
+    last_image = [-1]
 
-    def step(i):
-        si = i % nstreams                                         # steps alternate over the streams / contexts
+    def encode_image(n):
+        """n-th image of the run (n = step * ips + j)."""
+        si = n % nstreams                                         # images alternate over the streams / contexts
         with torch.cuda.stream(tstreams[si]):
             if gather is None:
-                b = i % nbuf
-                encs[si].encode_async(imgs[i % ROTATE], outs[b].data_ptr(), cap, sizes[b].data_ptr(), True,
-                                      tstreams[si].cuda_stream)
+                b = n % nbuf
+                encs[si].encode_async(imgs[n % nimg], outs[b].data_ptr(), cap, sizes[b].data_ptr(), True, tstreams[si].cuda_stream)
             else:
-                if i % G < nstreams:                              # a stream's first write into this buffer: behind the
-                    gather.reserve(i)                             # collective that last read it
-                optr, ocap, sptr = rec_ptrs[i % (2 * G)]
-                encs[si].encode_async(imgs[i % ROTATE], optr, ocap, sptr, True, tstreams[si].cuda_stream)
-                if i % G == G - 1:
-                    commit(i, False)
-        last_step[0] = i
+                if n % G < nstreams:                              # a stream's first write into this buffer: behind the
+                    gather.reserve(n)                             # collective that last read it
+                optr, ocap, sptr, _ = rec_ptrs[n % (2 * G)]
+                encs[si].encode_async(imgs[n % nimg], optr, ocap, sptr, True, tstreams[si].cuda_stream)
+                if n % G == G - 1:
+                    commit(n, False)
+        last_image[0] = n
 
-    def commit(i, force):
+    def step(i):
+        for j in range(ips):
+            encode_image(i * ips + j)
+
+    def commit(n, force):
         cur = torch.cuda.current_stream()
         for sj in tstreams:                                       # the buffer's records were produced on all streams
             if sj != cur:
                 cur.wait_event(sj.record_event())
-        gather.commit(i, force=force)
+        gather.commit(n, force=force)
 
     def drain():
-        if gather is not None and last_step[0] >= 0:
-            if last_step[0] % G != G - 1:
+        if gather is not None and last_image[0] >= 0:
+            if last_image[0] % G != G - 1:
                 with torch.cuda.stream(tstreams[0]):
-                    commit(last_step[0], True)
+                    commit(last_image[0], True)
             gather.wait_all()
         torch.cuda.synchronize()
+
+    def check_capacity(where):
+        """The capacity status is sticky on the device: finish() reports an overflow of ANY encode since the last finish."""
+        for e in encs:
+            try:
+                e.finish()
+            except jpegamd.JpegAmdError as err:
+                if err.code == -1:                                # nothing pending on this context
+                    continue
+                raise RuntimeError(f"bench.py: an encode in the {where} did not fit its output buffer ({err})")
 
     for i in range(W):
         step(i)
     drain()
-    for e in encs[:min(nstreams, W)]:
-        st = e.finish()                                           # also checks the capacity status of the last call
-        if st.jfif_bytes == 0:
-            raise RuntimeError("encode produced no output")
+    if W:
+        check_capacity("warm-up")
 
-    per_ctx = (K + nstreams - 1) // nstreams
+    n_timed = K * ips
+    per_ctx = (n_timed + nstreams - 1) // nstreams
     for e in encs:
         e.set_profiling(per_ctx)
     if dist is not None:
@@ -255,57 +306,68 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    last = (W + K - 1)
-    st = encs[last % nstreams].finish()
+    last = (W + K) * ips - 1
+    st = encs[last % nstreams].finish()                           # raises if ANY timed encode overflowed on that context
     for si, e in enumerate(encs):
-        if si != last % nstreams and K > si:
+        if si != last % nstreams and n_timed > si:
             e.finish()
+    if gather is not None:                                        # every record of the last buffers carries a plausible size
+        for k in range(min(2 * G, n_timed)):
+            n_bytes = int(rec_ptrs[k][3].item())
+            if not (0 < n_bytes <= rec_ptrs[k][1]):
+                raise RuntimeError(f"bench.py: gather record {k} holds {n_bytes} bytes (capacity {rec_ptrs[k][1]})")
 
     def mean_profile(pairs):
         prof = [e.profile(s) for e, n_calls in pairs for s in range(n_calls)]
         return tuple(sum(getattr(p, f) for p in prof) / max(1, len(prof)) for f in ("ns_transform", "ns_entropy", "ns_pack", "ns_total"))
 
-    ov_tr, ov_en, ov_pk, ov_tot = mean_profile([(e, len([i for i in range(W, W + K) if i % nstreams == si]))
+    first_timed = W * ips
+    ov_tr, ov_en, ov_pk, ov_tot = mean_profile([(e, len([n for n in range(first_timed, first_timed + n_timed) if n % nstreams == si]))
                                                  for si, e in enumerate(encs)])
     # Kernel durations for the roofline: with several streams the kernels of different images overlap in the
     # timed region, so an event pair no longer measures one kernel's own duration.  A short single-stream pass
-    # over the same rotating inputs gives the dominant kernel alone (this is what rocprofv3 --stats sees for
-    # `bench.py --streams 1`, profiles/).
+    # over the same inputs gives each kernel alone (this is what rocprofv3 --stats sees for `bench.py --streams 1`).
     if nstreams > 1:
-        P = min(K, 50)
+        P = min(n_timed, 60)
         encs[0].set_profiling(P)
         torch.cuda.synchronize()
         for i in range(P):
-            encs[0].encode_async(imgs[i % ROTATE], outs[0].data_ptr(), cap, sizes[0].data_ptr(), True,
-                                 tstreams[0].cuda_stream)
+            encs[0].encode_async(imgs[i % nimg], outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
         torch.cuda.synchronize()
         encs[0].finish()
         ns_tr, ns_en, ns_pk, ns_tot = mean_profile([(encs[0], P)])
-        roof_note = f"single-stream pass of {P} steps after the timed region"
+        roof_note = f"single-stream pass of {P} images after the timed region"
     else:
         ns_tr, ns_en, ns_pk, ns_tot = ov_tr, ov_en, ov_pk, ov_tot
         roof_note = "timed region (single stream)"
+    ns_sum = ns_tr + ns_en + ns_pk                                # sum of the kernels' own durations (no launch gaps)
 
-    # parity spot check of the last output against the committed natural_c golden (when present)
-    out_bytes = bytes(outs[last % nbuf][: int(sizes[last % nbuf].item())].cpu().numpy()) if (nstreams == 1 and gather is None) else None
-    if out_bytes is None:                                          # outs[] was reused (extra pass) or bypassed (gather records): re-encode `last`
-        encs[0].encode_async(imgs[last % ROTATE], outs[1].data_ptr(), cap, sizes[1].data_ptr(), True, tstreams[0].cuda_stream)
-        encs[0].finish()
-        out_bytes = bytes(outs[1][: int(sizes[1].item())].cpu().numpy())
-    parity = "unchecked"
-    gold = ROOT / "tests" / "golden" / "large.json"
-    if gold.exists() and rank == 0:
-        key = f"{w}x{h}_seed{1000 + rank * ROTATE + last % ROTATE}_kind{args.kind}_q{args.quality}"
-        ent = json.loads(gold.read_text()).get(key)
+    # parity spot check of the last image against the committed natural_c golden
+    encs[0].encode_async(imgs[last % nimg], outs[1].data_ptr(), cap, sizes[1].data_ptr(), True, tstreams[0].cuda_stream)
+    encs[0].finish()
+    out_bytes = bytes(outs[1][: int(sizes[1].item())].cpu().numpy())
+    parity, parity_ok = "unchecked", True
+    gold_file = ROOT / "tests" / "golden" / ("large.json" if workload == "image8192" else "batch4096.json")
+    if gold_file.exists() and rank == 0:
+        key = f"{w}x{h}_seed{seeds[last % nimg]}_kind{args.kind}_q{args.quality}"
+        ent = json.loads(gold_file.read_text()).get(key)
         if ent:
-            ok = ent["sha256"] == hashlib.sha256(out_bytes).hexdigest() and ent["size"] == len(out_bytes)
-            parity = "sha256 == natural_c golden" if ok else "MISMATCH vs natural_c golden"
+            parity_ok = ent["sha256"] == hashlib.sha256(out_bytes).hexdigest() and ent["size"] == len(out_bytes)
+            parity = "sha256 == natural_c golden" if parity_ok else "MISMATCH vs natural_c golden"
 
     if gather is not None and rank == 0:
-        per_rank = gather.result(W + K - 1)
-        used = (W + K - 1) % G + 1 if (W + K) % G else G
+        per_rank = gather.result(last)
+        used = last % G + 1
         if len(per_rank) != world or any(s[:2] != b"\xff\xd8" or s[-2:] != b"\xff\xd9" for r in per_rank for s in r[:used]):
             raise RuntimeError("gathered streams are not complete JFIF files")
+        if workload == "batch4096" and gold_file.exists() and args.kind == 0 and args.quality == 50:
+            gold = json.loads(gold_file.read_text())               # every gathered stream of the last buffer against the reference
+            for r in range(world):
+                for k in range(used):
+                    n = last - (used - 1) + k
+                    ent = gold.get(f"{w}x{h}_seed{2000 + r * BATCH_PER_RANK + n % nimg}_kind0_q50")
+                    if ent and hashlib.sha256(per_rank[r][k]).hexdigest() != ent["sha256"]:
+                        parity, parity_ok = f"MISMATCH vs natural_c golden (rank {r}, image {n})", False
 
     if rank != 0:
         if dist is not None:
@@ -319,12 +381,12 @@ def main():
     tf = ROOT / "profiles" / "hbm_traffic.json"
     if tf.exists():
         try:
-            traffic = json.loads(tf.read_text()).get(f"{w}x{h}_kind{args.kind}", {}).get("dominant_kernel_bytes_per_launch")
+            traffic = json.loads(tf.read_text()).get(f"{w}x{h}_kind{args.kind}", {}).get("pipeline_bytes_per_image")
         except Exception:
             traffic = None
     line = {
         "metric": "Mpixels/s encode (BMP -> grayscale baseline JPEG, bit-exact vs natural_c)",
-        "value": round(world * mpx * K / elapsed, 1),
+        "value": round(world * ips * mpx * K / elapsed, 1),
         "unit": "Mpixels/s",
         "n_gpus": world,
         "steps": K,
@@ -335,19 +397,22 @@ def main():
         "vs_baseline": None,
         "dtype": "u8 in, f32 DCT, int16 coefficients",
         "data": "synthetic",
-        "config": {"workload": f"{w}x{h} synthetic RGB BMP (kind {args.kind}), Q={args.quality}, 1 image/step/rank, "
-                               f"{ROTATE} rotating inputs/rank", "images_per_step": world,
+        "config": {"workload": (f"{w}x{h} synthetic RGB BMP (kind {args.kind}), Q={args.quality}, {ips} image(s)/step/rank, "
+                                f"{nimg} distinct inputs/rank" + (" (BASELINE configs[3]: batch of 64 at 8 ranks)" if workload == "batch4096" else
+                                                                   " (BASELINE configs[2])")),
+                   "images_per_step": world * ips,
                    "streams_per_rank": nstreams,
                    "parallelism": f"dp{world} (independent images per rank"
-                                  + (", async RCCL gather of bitstreams to rank 0)" if world > 1 else ")")},
-        "roofline": {"bound": "hbm", "kernel": "k_tile_transform",
-                     "achieved": round(algo_bytes / ns_tr, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(algo_bytes / ns_tr / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes": algo_bytes, "kernel_us": round(ns_tr / 1e3, 2),
-                     "entropy_us": round(ns_en / 1e3, 2), "pack_us": round(ns_pk / 1e3, 2),
-                     "all_kernels_us": round(ns_tot / 1e3, 2),
-                     "pipeline_frac": round(algo_bytes / ns_tot / HBM_PEAK_GBS, 4),
-                     "throughput_frac": round(algo_bytes / (elapsed / K * 1e9) / HBM_PEAK_GBS, 4),
+                                  + (", async RCCL gather of bitstreams to rank 0)" if dist is not None else ")")},
+        "roofline": {"bound": "hbm", "kernel": "k_tile_transform + k_entropy + k_finalize (sum of durations, SURVEY.md 8d)",
+                     "achieved": round(algo_bytes / ns_sum, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(algo_bytes / ns_sum / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes": algo_bytes,
+                     "hbm_read_frac": round(read_bytes / ns_sum / HBM_PEAK_GBS, 4),
+                     "dominant_kernel": "k_tile_transform", "dominant_frac": round(algo_bytes / ns_tr / HBM_PEAK_GBS, 4),
+                     "kernel_us": round(ns_tr / 1e3, 2), "entropy_us": round(ns_en / 1e3, 2), "pack_us": round(ns_pk / 1e3, 2),
+                     "sum_kernels_us": round(ns_sum / 1e3, 2), "first_to_last_event_us": round(ns_tot / 1e3, 2),
+                     "throughput_frac": round(algo_bytes * ips / (elapsed / K * 1e9) / HBM_PEAK_GBS, 4),
                      "measured": roof_note,
                      "overlapped_us": {"transform": round(ov_tr / 1e3, 2), "entropy": round(ov_en / 1e3, 2),
                                        "pack": round(ov_pk / 1e3, 2), "total": round(ov_tot / 1e3, 2)}},
@@ -358,13 +423,13 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         try:
-            line["cpu_baseline"] = cpu_baseline(first_bmp, args)
+            line["cpu_baseline"] = cpu_baseline(first_bmp, args, w, h)
         except Exception as e:                                    # a missing checker must not hide the GPU number
             line["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(line), file=json_out, flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    return 0
+    return 0 if parity_ok else 3
 
 
 if __name__ == "__main__":

@@ -37,6 +37,8 @@ struct Slot {
     uint8_t *h_in = nullptr, *d_in = nullptr, *d_out = nullptr, *h_out = nullptr;
     uint64_t *d_size = nullptr, *h_size = nullptr;
     size_t in_cap = 0, out_cap = 0;
+    size_t d_in_cap = 0;
+    JpegAmdImage img_inflight;                 // the file being encoded (for the second attempt with a worst-case buffer)
     int32_t enc_w = 0, enc_h = 0;
     int file = -1;                  // index of the file in flight, -1 = idle
     int32_t status = 0;
@@ -64,16 +66,25 @@ struct Slot {
         if (d_size) hipFree(d_size);
         enc = nullptr; stream = nullptr; size_ready = h2d_done = nullptr;
         h_in = d_in = d_out = h_out = nullptr; d_size = h_size = nullptr;
-        in_cap = out_cap = 0; file = -1;
+        in_cap = d_in_cap = out_cap = 0; file = -1;
     }
+    // The pinned host buffer is grown by the reader thread (the previous upload from it has completed: h2d_done); the DEVICE
+    // buffer only by the submitting thread, after the slot's previous file has been drained -- its kernels read d_in, and a
+    // file that did not fit its output buffer is encoded a second time from it.
     bool grow_in(size_t n) {
         if (n <= in_cap) return true;
         if (h_in) hipHostFree(h_in);
-        if (d_in) hipFree(d_in);
-        h_in = d_in = nullptr; in_cap = 0;
+        h_in = nullptr; in_cap = 0;
         if (hipHostMalloc((void **)&h_in, n, hipHostMallocDefault) != hipSuccess) return false;
-        if (hipMalloc((void **)&d_in, n) != hipSuccess) return false;
         in_cap = n;
+        return true;
+    }
+    bool grow_dev_in(size_t n) {
+        if (n <= d_in_cap) return true;
+        if (d_in) hipFree(d_in);
+        d_in = nullptr; d_in_cap = 0;
+        if (hipMalloc((void **)&d_in, n) != hipSuccess) return false;
+        d_in_cap = n;
         return true;
     }
     bool grow_out(size_t n) {
@@ -152,12 +163,13 @@ int32_t submit(Slot &s, int index, int32_t quality) {
     const uint64_t cap = jpegamd_max_jfif_bytes(img.width, img.height);
     // the output buffer is sized for typical content (1 byte per pixel + container); the encoder reports -8 beyond it
     const size_t out_cap = (size_t)img.width * (size_t)img.height + 4096 < cap ? (size_t)img.width * (size_t)img.height + 4096 : (size_t)cap;
-    if (!s.grow_out(out_cap)) return give_back(JPEGAMD_ERR_HIP, false);
+    if (!s.grow_out(out_cap) || !s.grow_dev_in(bytes)) return give_back(JPEGAMD_ERR_HIP, false);
     if (hipMemcpyAsync(s.d_in, s.h_in + off, bytes, hipMemcpyHostToDevice, s.stream) != hipSuccess) return give_back(JPEGAMD_ERR_HIP, false);
     if (hipEventRecord(s.h2d_done, s.stream) != hipSuccess) { hipStreamSynchronize(s.stream); return give_back(JPEGAMD_ERR_HIP, false); }
     s.in_bytes = (uint64_t)got;
     img.pixels = s.d_in;
     img.quality = quality;
+    s.img_inflight = img;
     rc = jpegamd_encode_async(s.enc, &img, s.d_out, s.out_cap, s.d_size, 1, (void *)s.stream);
     if (rc) return give_back(rc, true);
     if (hipMemcpyAsync(s.h_size, s.d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream) != hipSuccess) return give_back(JPEGAMD_ERR_HIP, true);
@@ -169,8 +181,18 @@ int32_t submit(Slot &s, int index, int32_t quality) {
 int32_t drain(Slot &s, const char *path, uint64_t *out_bytes, double *t_write) {
     if (hipEventSynchronize(s.size_ready) != hipSuccess) return JPEGAMD_ERR_HIP;
     int32_t rc = jpegamd_encoder_finish(s.enc, nullptr);      // status of the call (-8 when the stream outgrew the buffer)
+    uint64_t n = *s.h_size;
+    if (rc == JPEGAMD_ERR_HUFF_CAPACITY || (rc == JPEGAMD_OK && n > s.out_cap)) {
+        // The buffer is sized for typical content (1 byte per pixel); noise-like content at high quality needs more.
+        // Second attempt with the worst-case size (the pixels are still in d_in: nothing touches it before this drain).
+        const uint64_t worst = jpegamd_max_jfif_bytes(s.img_inflight.width, s.img_inflight.height);
+        if (!s.grow_out((size_t)worst)) return JPEGAMD_ERR_HIP;
+        rc = jpegamd_encode_async(s.enc, &s.img_inflight, s.d_out, s.out_cap, s.d_size, 1, (void *)s.stream);
+        if (rc == JPEGAMD_OK && hipMemcpyAsync(s.h_size, s.d_size, sizeof(uint64_t), hipMemcpyDeviceToHost, s.stream) != hipSuccess) rc = JPEGAMD_ERR_HIP;
+        if (rc == JPEGAMD_OK) rc = jpegamd_encoder_finish(s.enc, nullptr);
+        n = *s.h_size;
+    }
     if (rc) return rc;
-    const uint64_t n = *s.h_size;
     if (n == 0 || n > s.out_cap) return JPEGAMD_ERR_HUFF_CAPACITY;
     if (hipMemcpyAsync(s.h_out, s.d_out, (size_t)n, hipMemcpyDeviceToHost, s.stream) != hipSuccess) return JPEGAMD_ERR_HIP;
     if (hipStreamSynchronize(s.stream) != hipSuccess) return JPEGAMD_ERR_HIP;

@@ -204,25 +204,51 @@ class ShardedImageEncoder:
 
     def encode(self, img, out: torch.Tensor, out_size: torch.Tensor, with_container: bool = True, stream: int = 0) -> None:
         """Collective: every rank calls it with the same image description (its `pixels` must cover the rank's rows and
-        the block row above).  On `dst` the JFIF bytes land in `out`, their count in `out_size` (device int64)."""
+        the block row above).  On `dst` the JFIF bytes land in `out`, their count in `out_size` (device int64).
+
+        Everything -- kernels AND collectives -- is ordered on ONE stream (`stream`, a raw HIP stream handle, or torch's
+        current stream): the collectives are issued with that stream current, so RCCL orders them behind the export
+        kernels and the import / finalize kernels behind them.  Only the words actually used travel: one MAX all-reduce of
+        the ranks' word totals sizes the gather (this is the one host synchronisation of the call) and doubles as the
+        capacity check of every rank's pack.  With a gloo group (CPU tests, or several processes sharing one GPU) the
+        packs are staged through host memory."""
         by0, by1 = self.rows_of(self.rank)
-        self.enc.encode_rows_async(img, by0, by1, stream)
-        self.enc.export_segments(img, by0, by1, self.dense.data_ptr(), self.max_words, self.meta.data_ptr(), self.total.data_ptr(), stream)
-        if self.world == 1:
-            self.enc.finalize_async(img, out.data_ptr(), out.numel(), out_size.data_ptr(), with_container, stream)
-            return
-        # one padded gather per buffer: the pad is the allocation, the payload size travels inside `meta`
-        g1 = dist.gather(self.dense, self.recv_dense if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
-        g2 = dist.gather(self.meta, self.recv_meta if self.rank == self.dst else None, dst=self.dst, group=self.group, async_op=True)
-        g1.wait()
-        g2.wait()
-        if self.rank == self.dst:
-            for r in range(self.world):
-                if r == self.rank:
-                    continue                                              # the root's own segments are already in place
-                b0, b1 = self.rows_of(r)
-                self.enc.import_segments(img, b0, b1, self.recv_dense[r].data_ptr(), self.recv_meta[r].data_ptr(), stream)
-            self.enc.finalize_async(img, out.data_ptr(), out.numel(), out_size.data_ptr(), with_container, stream)
+        ts = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+        with torch.cuda.stream(ts):
+            raw = ts.cuda_stream
+            self.enc.encode_rows_async(img, by0, by1, raw)
+            self.enc.export_segments(img, by0, by1, self.dense.data_ptr(), self.max_words, self.meta.data_ptr(), self.total.data_ptr(), raw)
+            if self.world == 1:
+                self.enc.finalize_async(img, out.data_ptr(), out.numel(), out_size.data_ptr(), with_container, raw)
+                return
+            on_host = dist.get_backend(self.group) == "gloo"
+            biggest = self.total.to(torch.int64).cpu() if on_host else self.total.to(torch.int64)
+            dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=self.group)
+            n = int(biggest.item())                                    # host waits here: the words of the fattest pack
+            if n > self.max_words:
+                raise RuntimeError(f"a rank's segment pack needs {n} words, the exchange buffers hold {self.max_words}")
+            n = max(n, 1)
+            root = self.rank == self.dst
+            if on_host:
+                d_h, m_h = self.dense[:n].cpu(), self.meta.cpu()
+                rd = [torch.empty_like(d_h) for _ in range(self.world)] if root else None
+                rm = [torch.empty_like(m_h) for _ in range(self.world)] if root else None
+                dist.gather(d_h, rd, dst=self.dst, group=self.group)
+                dist.gather(m_h, rm, dst=self.dst, group=self.group)
+                if root:
+                    for r in range(self.world):
+                        self.recv_dense[r][:n].copy_(rd[r], non_blocking=False)
+                        self.recv_meta[r].copy_(rm[r], non_blocking=False)
+            else:
+                dist.gather(self.dense[:n], [t[:n] for t in self.recv_dense] if root else None, dst=self.dst, group=self.group)
+                dist.gather(self.meta, self.recv_meta if root else None, dst=self.dst, group=self.group)
+            if root:
+                for r in range(self.world):
+                    if r == self.rank:
+                        continue                                          # the root's own segments are already in place
+                    b0, b1 = self.rows_of(r)
+                    self.enc.import_segments(img, b0, b1, self.recv_dense[r].data_ptr(), self.recv_meta[r].data_ptr(), raw)
+                self.enc.finalize_async(img, out.data_ptr(), out.numel(), out_size.data_ptr(), with_container, raw)
 
 
 def encode_image_virtual_ranks(jpegamd, img, width: int, height: int, ranks: int, device, root_encoder=None):

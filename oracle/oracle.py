@@ -16,6 +16,7 @@ HERE = Path(__file__).resolve().parent
 LIB = HERE / "liboracle.so"
 REF_APP = HERE / "_ref" / "jpeg_compression_app"
 REF_LIB = HERE / "_ref" / "libnatural_c_ref.so"
+REF_LIB_O2 = HERE / "_ref" / "libnatural_c_ref_O2.so"      # the reference's sources with -O2 added (second CPU baseline)
 
 
 def build(ref: bool = True) -> None:

@@ -349,6 +349,19 @@ def test_file_batch_pipeline_matches_oracle(jpegamd, oracle, dev, tmp_path):
     # all files readable -> return code 0
     rc2, status2, st2 = jpegamd.encode_files(ins[:3], outs[:3])
     assert rc2 == 0 and status2 == [0, 0, 0] and st2.files_failed == 0
+    # noise at quality 100 needs more than the 1 byte per pixel the batch path reserves: the file is encoded a second time
+    # into a worst-case buffer instead of failing with -8 (saveJPEGGrayscale / encode_bmp_memory always could)
+    noisy = [jpegamd.synth_bmp(256, 192, 21, 1, 0), jpegamd.synth_bmp(640, 480, 11, 0, 0), jpegamd.synth_bmp(200, 200, 22, 1, 0)]
+    nin, nout = [], []
+    for i, bmp in enumerate(noisy):
+        (tmp_path / f"n_{i}.bmp").write_bytes(bmp)
+        nin.append(tmp_path / f"n_{i}.bmp"); nout.append(tmp_path / f"n_{i}.jpg")
+    rc3, status3, _ = jpegamd.encode_files(nin, nout, quality=100)
+    assert rc3 == 0 and status3 == [0, 0, 0]
+    for i, bmp in enumerate(noisy):
+        exp = oracle.encode_bmp(bmp, 100)
+        assert nout[i].read_bytes() == exp, f"noisy file {i}"
+    assert len(oracle.encode_bmp(noisy[0], 100)) > 256 * 192 + 4096          # the case really exceeds the first buffer
 
 
 @pytest.mark.gpu
@@ -398,6 +411,21 @@ def test_sharded_image_encoder_single_rank(jpegamd, oracle, dev):
     enc.finish()
     assert bytes(out[:int(size.item())].cpu().numpy()) == oracle.encode_bmp(bmp)
     assert int(she.total.item()) > 0 and she.rows_of(0) == (0, (h + 7) // 8)
+
+
+@pytest.mark.gpu
+def test_sharded_image_encoder_two_processes(jpegamd, oracle, dev, tmp_path):
+    """SURVEY.md 8e, one image over several ranks, with world_size 2 for real: two fresh processes (a gloo group; both on
+    GPU 0, packs staged through host memory) each transform and entropy-code their block rows, the root imports the other
+    rank's segments at their global indices and finalizes.  Even split, ragged split (odd number of block rows), several
+    segments per row, noise (stuffing across the seam): bytes equal the oracle's (rle.c:59-70 DC chain, huffman.c:35-81)."""
+    import torch.multiprocessing as mp
+    import sharded_worker
+    cases = [(640, 480, 31, 0), (2100, 333, 32, 1), (4200, 168, 33, 0), (300, 72, 34, 1)]
+    mp.spawn(sharded_worker.run, args=(2, 29533, cases, str(tmp_path)), nprocs=2, join=True)
+    for ci, (w, h, seed, kind) in enumerate(cases):
+        got = (tmp_path / f"case{ci}.jpg").read_bytes()
+        assert got == oracle.encode_bmp(jpegamd.synth_bmp(w, h, seed, kind, 0)), (w, h, kind)
 
 
 @pytest.mark.gpu

@@ -13,7 +13,7 @@ for v in default "$@"; do
   python - <<PY
 import json
 d=json.load(open("$O/bench_$v.json")); r=d["roofline"]
-print("%-10s value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % ("$v", d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["all_kernels_us"], d["parity"]))
+print("%-10s value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % ("$v", d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["sum_kernels_us"], d["parity"]))
 PY
 done
 done

@@ -11,6 +11,6 @@ timeout -k 10 200 python bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-b
 python - <<PY
 import json
 d=json.load(open("$O/bench_s1.json")); r=d["roofline"]
-print("value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % (d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["all_kernels_us"], d["parity"]))
+print("value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % (d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["sum_kernels_us"], d["parity"]))
 PY
 bash tools/gpu_trace.sh > $O/trace.txt 2>&1; cat $O/trace.txt | grep -v rocclr

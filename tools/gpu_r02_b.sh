@@ -11,7 +11,7 @@ for v in default contig default contig; do
   python - <<PY
 import json
 d=json.load(open("$O/bench_$v.json")); r=d["roofline"]
-print("%-10s value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % ("$v", d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["all_kernels_us"], d["parity"]))
+print("%-10s value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % ("$v", d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["sum_kernels_us"], d["parity"]))
 PY
 done
 JPEGAMD_LIB=$PWD/build_variants/lib_stamps.so timeout -k 10 200 python tools/stamp_profile_tile.py > $O/stamps.txt 2>&1 || { tail -20 $O/stamps.txt; exit 1; }

@@ -10,7 +10,7 @@ for f in build_variants/lib_*.so; do
   python - <<PY
 import json
 d=json.load(open("gpurun_out/v_$n.json")); r=d["roofline"]
-print("%-10s streams $s value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % ("$n", d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["all_kernels_us"], d["parity"]))
+print("%-10s streams $s value %.0f  transform %.2f  entropy %.2f  pack %.2f  total %.2f  %s" % ("$n", d["value"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["sum_kernels_us"], d["parity"]))
 PY
   done
 done
