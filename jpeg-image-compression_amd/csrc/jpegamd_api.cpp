@@ -40,6 +40,7 @@ struct JpegAmdEncoder {
     MfmaTables *tables_dev = nullptr;
     MfmaTables *tables_host = nullptr;          // this context's own staging copy (contexts may be driven from different threads)
     uint32_t *tile_items = nullptr, *tile_ctr = nullptr;
+    int ctr_set = 0;                    // which half of tile_ctr the next k_tile_transform launch uses
     unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
     // cached constants
     int cur_quality = -1;
@@ -160,8 +161,8 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY_CREATE(hipMemset(e->stats_dev, 0, sizeof(ScanStats)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->tile_items, (size_t)e->max_tiles * kTileItemCap * sizeof(uint32_t)));
-    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_ctr, 64 * 128));          // ticket-group cache lines
-    HIP_TRY_CREATE(hipMemset(e->tile_ctr, 0, 64 * 128));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_ctr, 2 * 64 * 128));      // two sets of ticket-group cache lines, used alternately
+    HIP_TRY_CREATE(hipMemset(e->tile_ctr, 0, 2 * 64 * 128));
     if (std::getenv("JPEGAMD_STAMPS")) {
         const size_t n = (size_t)(e->max_segs > 4096 ? e->max_segs : 4096) * 16 * sizeof(unsigned long long);
         HIP_TRY_CREATE(hipMalloc((void **)&e->stamps_dev, n));
@@ -271,8 +272,13 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     std::memset(&to, 0, sizeof(to));
     to.tables = e->tables_dev; to.stamps = e->stamps_dev;
     to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
-    to.tile_items = e->tile_items; to.tile_ctr = e->tile_ctr;
+    to.tile_items = e->tile_items;
+    // Launches on one context are stream-ordered by contract (they share the scratch): launch i draws tickets from set
+    // i % 2 and zeroes the other one for launch i + 1.
+    to.tile_ctr = e->tile_ctr + (e->ctr_set ? 64 * 32 : 0);
+    to.tile_ctr_next = e->tile_ctr + (e->ctr_set ? 0 : 64 * 32);
     if (int err = launch_tile_transform(im, to, taps, stream)) return err;
+    if (im.tile_end > im.tile_begin) e->ctr_set ^= 1;      // (an empty range launches nothing)
     if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
     EntropyArgs ea;
     std::memset(&ea, 0, sizeof(ea));

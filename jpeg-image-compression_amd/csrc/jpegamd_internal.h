@@ -84,7 +84,8 @@ struct SegArrays {
 struct TransformOutM {
     const MfmaTables *tables;   // device copy
     uint32_t *tile_items;       // [num_tiles][kTileItemCap]
-    uint32_t *tile_ctr;         // [64 groups][32 words]: word 0 ticket counter of the dynamic tile hand-out, word 1 waves finished; zero between launches
+    uint32_t *tile_ctr;         // [64 groups][32 words]: word 0 = ticket counter of the group's tile hand-out; zero at launch
+    uint32_t *tile_ctr_next;    // the set the NEXT launch on this context uses: zeroed by this launch
     unsigned long long *stamps; // per-wave phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
     int8_t *tap_y;              // stage taps (debug variant only)
     int16_t *tap_zz;

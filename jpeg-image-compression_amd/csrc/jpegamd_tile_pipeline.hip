@@ -111,9 +111,6 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 #define TSTAMP(i) do { } while (0)
 #endif
 
-#ifndef JPEGAMD_TILE_SPREAD
-#define JPEGAMD_TILE_SPREAD 0
-#endif
 #ifndef JPEGAMD_TILE_GROUPS
 #define JPEGAMD_TILE_GROUPS 64
 #endif
@@ -124,8 +121,17 @@ constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket count
 #ifndef JPEGAMD_TILE_WAVES
 #define JPEGAMD_TILE_WAVES 4
 #endif
-#ifndef JPEGAMD_TILE_INTERLEAVE
-#define JPEGAMD_TILE_INTERLEAVE 1
+#ifndef JPEGAMD_COPY_STORES
+#define JPEGAMD_COPY_STORES 4
+#endif
+#ifndef JPEGAMD_COPY_AUX
+#define JPEGAMD_COPY_AUX 0           // cache policy bits of the closing stores
+#endif
+constexpr int kCopyStores = JPEGAMD_COPY_STORES;                 // 16-byte-per-lane stores that close every iteration
+constexpr int kStageItems = kCopyStores * 256 - 1;               // longest list built in LDS (+ its padding item)
+static_assert(kCopyStores * 256 <= 8 * 132, "the staged list lives in the tile's luma buffer");
+#ifndef JPEGAMD_TILE_STEAL
+#define JPEGAMD_TILE_STEAL 0          // partner groups a wave may draw tiles from once its own group is dry
 #endif
 
 struct TileSched {            // division-free launch geometry, filled by launch_tile_transform
@@ -182,41 +188,40 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     // image; exact-order events), so a static split of 8 tiles per wave leaves SIMDs idle behind the slowest wave
     // (per-wave totals: max/mean 1.5, tools/stamp_profile_tile.py).  One global ticket per tile is no answer
     // either: same-address device atomics retire at ~12 ns each (measured: 6x slower).  So the workgroups form
-    // kTileGroups groups (blockIdx % groups: the members of a group sit on one XCD), each group owns a contiguous
-    // range of tiles and hands them to its waves through its OWN ticket counter (own cache line).  The ticket for
-    // the tile after next is requested one iteration ahead, so its latency is hidden like the pixel rows'.
+    // kTileGroups groups (blockIdx % groups: the members of a group sit on one XCD), each group owns a share of the
+    // tiles and hands them to its waves through its OWN ticket counter (own cache line).
     const int groups = 1 << sch.grp_shift;
-#if JPEGAMD_TILE_SPREAD
-    // Members of a ticket group on DIFFERENT XCDs (consecutive workgroups; blocks are dealt round-robin over the XCDs):
-    // the XCDs hold different clocks under this load (1.87 .. 2.06 GHz measured), a group confined to one of them
-    // finishes up to 10 % early or late.  Needs a grid that is a multiple of the group count (else: identity).
-    const int members = (int)gridDim.x >> sch.grp_shift;
-    const int bid = (members << sch.grp_shift) == (int)gridDim.x ? ((int)blockIdx.x % members) * groups + (int)blockIdx.x / members
-                                                                  : (int)blockIdx.x;
-#else
     const int bid = (int)blockIdx.x;
-#endif
     const int grp = bid & (groups - 1);
-    const int grp_waves = ((((int)gridDim.x - 1 - grp) >> sch.grp_shift) + 1) * kWavesT;   // waves of this group
-#if JPEGAMD_TILE_INTERLEAVE
-    // A group owns the CHUNKS (kWavesT consecutive tiles, what its 8 waves work on side by side) c = grp, grp + groups, ...
-    // and walks them in order: content density varies slowly over the picture, so contiguous ranges per group left
-    // the densest group 10-20 % behind the mean (profiles/r02_stamps_r01_kernel.txt: workgroup means 77 k .. 92 k cycles).
-    // Below, grp_lo / grp_hi / tile indices of the loop are GROUP-LOCAL; to_tile() maps them to picture tiles.
+    const int gmask = groups - 1;
+    const auto waves_of = [&](int g) { return ((((int)gridDim.x - 1 - g) >> sch.grp_shift) + 1) * kWavesT; };   // waves of group g
+    // A group owns one CHUNK (kWavesT consecutive tiles, what its 8 waves work on side by side) of every STEP of `groups`
+    // consecutive chunks, and walks its chunks in order: content density varies slowly over the picture, so contiguous
+    // ranges per group left the densest group 10-20 % behind the mean (profiles/r02_stamps_r01_kernel.txt).  Within step k
+    // the group takes slot (g + k) mod groups: with a fixed slot a group kept to ONE column band of the picture (8192
+    // wide: 4 chunks per row, 64 % 4 == 0), and the bands differ (workgroup means 77 k .. 93 k cycles,
+    // profiles/r02_stamps_interleaved.txt).
+    // Tile indices of the loop (li, nxt, cur_hi) are GROUP-LOCAL; to_tile() maps them to picture tiles.
     const int ntl = im.tile_end - im.tile_begin;
-    const int nchunks = (ntl + kWavesT - 1) / kWavesT;
-    const int my_chunks = grp < nchunks ? ((nchunks - 1 - grp) >> sch.grp_shift) + 1 : 0;
-    const bool owns_last = my_chunks > 0 && ((nchunks - 1) & (groups - 1)) == grp;
-    const int grp_lo = 0;
-    const int grp_hi = my_chunks * kWavesT - (owns_last ? nchunks * kWavesT - ntl : 0);
-    const auto to_tile = [&](int li) { return im.tile_begin + ((((li / kWavesT) << sch.grp_shift) + grp) * kWavesT) + (li % kWavesT); };
-#else
-    const int grp_lo = min(im.tile_begin + grp * sch.tiles_per_group, im.tile_end);
-    const int grp_hi = min(grp_lo + sch.tiles_per_group, im.tile_end);
-    const auto to_tile = [&](int li) { return li; };
-#endif
-    uint32_t *ctr = out.tile_ctr + grp * 32;                                                // [0] tickets, [1] waves done
-    const int first = grp_lo + (bid >> sch.grp_shift) * kWavesT + wave;
+    const int nchunks = (ntl + kWavesT - 1) / kWavesT;                       // >= 1 (launch_tile_transform)
+    const int full_steps = nchunks >> sch.grp_shift, rem = nchunks & gmask;
+    const int last_owner = (((nchunks - 1) & gmask) - ((nchunks - 1) >> sch.grp_shift)) & gmask;   // group of the last (maybe short) chunk
+    const auto tiles_of = [&](int g) {                                       // group-local tile count of group g
+        const int chunks = full_steps + ((rem > 0 && ((g + full_steps) & gmask) < rem) ? 1 : 0);
+        return chunks * kWavesT - (g == last_owner ? nchunks * kWavesT - ntl : 0);
+    };
+    // The group this wave currently draws tiles from: its own, then (JPEGAMD_TILE_STEAL levels) the groups grp ^ 1, grp ^ 2, ...
+    // -- members of other XCDs (XCD = workgroup % 8 = grp % 8), whose clocks differ by up to 10 % under this load.
+    int cur_grp = grp, cur_hi = tiles_of(grp), cur_waves = waves_of(grp);
+    [[maybe_unused]] int steal_level = 0;
+    const auto to_tile = [&](int li) {
+        const int k = li / kWavesT;
+        return im.tile_begin + (((k << sch.grp_shift) + ((cur_grp + k) & gmask)) * kWavesT) + (li % kWavesT);
+    };
+    uint32_t *ctr = out.tile_ctr + grp * 32;                                 // word 0: tickets handed out
+    // This launch's counters were zeroed by the previous launch on this context; zero the next launch's (the other set).
+    if (bid == 0 && threadIdx.x < kTileGroups) out.tile_ctr_next[threadIdx.x * 32] = 0u;   // all of them: the next launch may form more groups
+    const int first = (bid >> sch.grp_shift) * kWavesT + wave;
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
     struct TileGeo { int by, tbx0, nblk, bx; bool interior; };
     const auto geo = [&](int tile) {
@@ -246,7 +251,8 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
     };
     RawRow raw[4];
-    TileGeo tg = geo(first < grp_hi ? to_tile(first) : im.tile_begin);
+    TileGeo tg = geo(first < cur_hi ? to_tile(first) : im.tile_begin);
+    if (first < cur_hi && tg.interior) request_rows(tg, raw);
 #ifdef JPEGAMD_STAMPS
     unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_last)::"memory");
@@ -254,7 +260,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #endif
 
 #pragma unroll 1
-    for (int li = first; li < grp_hi;) {
+    for (int li = first; li < cur_hi;) {
         const int tile = to_tile(li);
         const int by = tg.by, nblk = tg.nblk, bx = tg.bx;
         const int py0 = by * 8, px0 = bx * 8;
@@ -263,8 +269,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         TSTAMP(0);   // loop overhead / geometry
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         f16x8 bfrag[4];
-        if (interior) {
-            request_rows(tg, raw);
+        if (interior) {                        // rows requested one iteration ago, behind the ticket (below)
 #pragma unroll
             for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_f16(raw[s], lw, luma_kc);
         } else {
@@ -448,57 +453,118 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // The ticket requested at the top of the iteration is collected here, BEFORE the item stores are issued:
         // the wait for it then covers no younger memory operation (built with the atomic optimizer off -- its
         // expansion reads the result back, and waits for vmcnt(0), right behind the atomic).
-        const int nxt = grp_lo + grp_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
-        TileGeo tg_next = tg;
-        if (nxt < grp_hi) tg_next = geo(to_tile(nxt));
-        // ---- 6. append the items (from word 0 of the tile's list) ----
-        // Per stored item: one SDWA add writes the zigzag position into the upper half of the value's own register,
-        // one buffer store (32-bit offset against the tile's descriptor), one offset increment.
-        uint32_t *list = out.tile_items + (size_t)tile * kTileItemCap;
-        #ifdef JPEGAMD_NO_ITEM_STORE           // timing-only build: zero records, the range check drops every item store (stream, waits unchanged)
-        const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, 0, 0x00020000);
-#else
-        const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, kTileRecord * 4, 0x00020000);
+        int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
+#if JPEGAMD_TILE_STEAL
+        // Own group dry: draw from a partner group's counter (its waves cannot tell).  The ticket is waited for here, once or
+        // twice per wave at the very end of its work; a failed draw ends the wave.
+        while (nxt >= cur_hi && steal_level < JPEGAMD_TILE_STEAL && (1 << steal_level) < groups) {
+            cur_grp = grp ^ (1 << steal_level);
+            ++steal_level;
+            cur_hi = tiles_of(cur_grp);
+            cur_waves = waves_of(cur_grp);
+            ctr = out.tile_ctr + cur_grp * 32;
+            nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket());
+        }
 #endif
-        if (active) {
-            uint32_t off = 0;
+        TileGeo tg_next = tg;
+        if (nxt < cur_hi) tg_next = geo(to_tile(nxt));
+        // The next tile's pixel rows: 8 loads, in flight behind the appends.  vmcnt retires in issue order, so the wait at
+        // the top of the loop must not have to count a VARYING number of younger stores: whatever path the appends take,
+        // exactly kCopyStores stores close the iteration (the compiler then waits for vmcnt(kCopyStores), not 0).
+        if (nxt < cur_hi && tg_next.interior) {
+            request_rows(tg_next, raw);
+        } else {                               // (defined on every path: else the old rows stay live through the whole iteration)
 #pragma unroll
-            for (int G = 0; G < 4; ++G) {
-                if (!gact[G]) continue;
-                off = (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
-                const uint32_t zg = (uint32_t)(16 * G + 8 * h);
-                if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, JPEGAMD_ITEM_AUX); off += 4u; }
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
-                    if (v != 0) {
-                        uint32_t item = (uint32_t)v;
-                        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-                            : "+v"(item) : "v"(zg), "n"(j));
-                        __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
-                        off += 4u;
+                for (int i = 0; i < 6; ++i) raw[s].d[i] = 0u;
+        }
+        // ---- 6. append the items (from word 0 of the tile's list) ----
+        // Per item: one SDWA add writes the zigzag position into the upper half of the value's own register, one write, one
+        // offset increment.  Up to kStageItems items the list is built in LDS (the tile's luma there is dead by now) and leaves
+        // as whole 16-byte pieces per lane: 4-byte stores scattered over the list's lines cost one L2 request per lane-run and
+        // line (6.5 M requests per 8192^2 image, tools/ubench/launch_cost.hip: 30 us of L2 time on their own).
+        uint32_t *list = out.tile_items + (size_t)tile * kTileItemCap;
+        const bool staged = t_all <= (uint32_t)kStageItems;
+        uint32_t *stage = &s_pix[wave][0];
+        if (staged) {
+            if (active) {
+                uint32_t off = 0;
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    if (!gact[G]) continue;
+                    off = blk_base + ((starts >> (8 * G)) & 0xFFu);
+                    const uint32_t zg = (uint32_t)(16 * G + 8 * h);
+                    if (G == 0 && h == 0) { stage[off] = dc_item; off += 1u; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
+                        if (v != 0) {
+                            uint32_t item = (uint32_t)v;
+                            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                                : "+v"(item) : "v"(zg), "n"(j));
+                            stage[off] = item;
+                            off += 1u;
+                        }
                     }
                 }
+                if (eob) {
+                    if (!gact[3]) off = blk_base + (starts >> 24);
+                    stage[off] = kItEobValue;
+                }
             }
-            if (eob) {
-                if (!gact[3]) off = (blk_base + (starts >> 24)) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b32(kItEobValue, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
+            if (lane == 0 && (t_all & 1u)) stage[t_all] = kItPadValue;  // k_entropy's lanes take two items each: even count per list
+        } else {
+#ifdef JPEGAMD_NO_ITEM_STORE           // timing-only build: zero records, the range check drops every item store (stream, waits unchanged)
+            const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, 0, 0x00020000);
+#else
+            const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, kTileRecord * 4, 0x00020000);
+#endif
+            if (active) {
+                uint32_t off = 0;
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    if (!gact[G]) continue;
+                    off = (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
+                    const uint32_t zg = (uint32_t)(16 * G + 8 * h);
+                    if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, JPEGAMD_ITEM_AUX); off += 4u; }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
+                        if (v != 0) {
+                            uint32_t item = (uint32_t)v;
+                            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                                : "+v"(item) : "v"(zg), "n"(j));
+                            __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
+                            off += 4u;
+                        }
+                    }
+                }
+                if (eob) {
+                    if (!gact[3]) off = (blk_base + (starts >> 24)) * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(kItEobValue, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
+                }
             }
+            if (lane == 0 && (t_all & 1u)) list[t_all] = kItPadValue;
         }
-        if (lane == 0) {
-            if (t_all & 1u) list[t_all] = kItPadValue;                   // k_entropy's lanes take two items each: even count per list
+        if (lane == 0)
             *reinterpret_cast<uint4 *>(list + kTileRecord) =
                 make_uint4(t_all, (uint32_t)__builtin_amdgcn_readlane(n[0], nblk - 1), (uint32_t)nexact, 0u);
+        {   // the closing stores: 16 bytes per lane and store out of the staged list; lanes beyond it (all of them on the
+            // direct path) fall to the descriptor's range check.  Whole 16-byte pieces: the list's capacity is a multiple of 16.
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+            const uint32_t staged_bytes = staged ? ((t_all + 3u) & ~3u) * 4u : 0u;
+            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, staged_bytes, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < kCopyStores; ++i) {
+                const u32x4 piece = *reinterpret_cast<const u32x4 *>(&stage[i * 256 + lane * 4]);
+                __builtin_amdgcn_raw_buffer_store_b128(piece, crsrc, (uint32_t)(i * 1024 + lane * 16), 0, JPEGAMD_COPY_AUX);
+            }
         }
 #undef JPEGAMD_ACC
         TSTAMP(7);   // appends
         li = nxt;
         tg = tg_next;
-    }
-    // the last wave of the group re-arms its counters for the next launch on this context
-    if (lane == 0 && atomicAdd(ctr + 1, 1u) == (uint32_t)grp_waves - 1u) {
-        ctr[0] = 0u;
-        ctr[1] = 0u;
     }
 #ifdef JPEGAMD_STAMPS
     {   // [8] kernel entry, [9] loop start, [10] loop end in 100 MHz ticks; [11] shader cycles of the loop

@@ -1,6 +1,9 @@
 #!/bin/bash
+# in-kernel stamp profile of k_tile_transform (diagnostic builds build_variants/lib_stamps*.so)
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/stamps
-JPEGAMD_LIB=$PWD/build_variants/lib_stamps.so timeout -k 10 200 python tools/stamp_profile_tile.py > gpurun_out/stamps/stamps.txt 2>&1 || { tail -20 gpurun_out/stamps/stamps.txt; exit 1; }
-tail -14 gpurun_out/stamps/stamps.txt
+for v in stamps "$@"; do
+JPEGAMD_LIB=$PWD/build_variants/lib_$v.so timeout -k 10 200 python tools/stamp_profile_tile.py > gpurun_out/stamps/$v.txt 2>&1 || { tail -20 gpurun_out/stamps/$v.txt; exit 1; }
+echo "== $v"; tail -16 gpurun_out/stamps/$v.txt
+done
