@@ -15,7 +15,10 @@ namespace jpegamd {
 // tile    32 consecutive blocks of one block row: one wave-iteration of k_tile_transform, one 32-column MFMA operand
 // segment 8 consecutive tiles of one block row (<= 256 blocks): one wave of k_entropy, the unit of bitstream ownership
 constexpr int kTileBlocks = 32;
-constexpr int kSegTiles = 8;
+#ifndef JPEGAMD_SEG_TILES
+#define JPEGAMD_SEG_TILES 8
+#endif
+constexpr int kSegTiles = JPEGAMD_SEG_TILES;
 constexpr int kSegBlocks = kTileBlocks * kSegTiles;                  // 256
 // Worst case bits per block: DC 9+11, 63 x (16+11) AC (quality 100 -> 11-bit amplitudes).
 constexpr int kMaxBlockBits = 20 + 63 * 27;                          // 1721
@@ -48,6 +51,7 @@ struct MfmaTables {
     float bias;                    // 0.5 + max_z delta_z
     float pad[3];
     float grp_thr[8];              // [group G][lane half h]: |MFMA output| below it => zigzag 16G+8h .. +7 all quantise to an unflagged 0
+    float flag_thr[8];             // [group G][lane half h]: max qthr over zigzag 16G+8h .. +7
 };
 
 struct ScanStats {                   // device-side per-call record

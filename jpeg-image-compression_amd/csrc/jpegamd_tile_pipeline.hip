@@ -121,6 +121,21 @@ constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket count
 #ifndef JPEGAMD_TILE_WAVES
 #define JPEGAMD_TILE_WAVES 4
 #endif
+#ifndef JPEGAMD_TICKET_EARLY
+#define JPEGAMD_TICKET_EARLY 2       // where the next tile's ticket is requested: 0 before the exact-order phase, 1 at the top of the iteration, 2 behind the MFMAs
+#endif
+#ifndef JPEGAMD_FLAG_MINTREE
+#define JPEGAMD_FLAG_MINTREE 1
+#endif
+#ifndef JPEGAMD_BIAS_VGPR
+#define JPEGAMD_BIAS_VGPR 1
+#endif
+#ifndef JPEGAMD_THR_REGS
+#define JPEGAMD_THR_REGS 0
+#endif
+#ifndef JPEGAMD_APPEND_ASM
+#define JPEGAMD_APPEND_ASM 1
+#endif
 #ifndef JPEGAMD_COPY_STORES
 #define JPEGAMD_COPY_STORES 4
 #endif
@@ -140,6 +155,39 @@ struct TileSched {            // division-free launch geometry, filled by launch
     uint32_t tpr_magic;       // floor(2^32 / tiles_per_row) + 1: tile / tiles_per_row by multiply-high (+ one correction)
 };
 
+// Appends of one group's sites to the staged list, branch-free: per site one compare that narrows EXEC to the lanes holding
+// a non-zero value, the SDWA add that writes the zigzag position into the value's upper half, the LDS write, the address
+// increment (5 issue slots; the compiler's version costs 4 slots for a site no lane uses and ~10, with a taken branch, for
+// the others).  `addr` is the byte address in LDS of the lane's next item; values are modified in place.
+#define JPEGAMD_APPEND_SITE(V, J)                                                                                       \
+    "v_cmpx_ne_u32_e32 0, %[" #V "]\n\t"                                                                                \
+    "v_add_u32_sdwa %[" #V "], %[zg], " #J " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
+    "ds_write_b32 %[addr], %[" #V "]\n\t"                                                                               \
+    "v_add_u32_e32 %[addr], 4, %[addr]\n\t"                                                                            \
+    "s_mov_b64 exec, %[save]\n\t"
+template <bool kSkipFirst>
+__device__ __forceinline__ void append_group_lds(uint32_t &addr, int (&v)[8], uint32_t zg) {
+    uint64_t save;
+    if (kSkipFirst) {
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     JPEGAMD_APPEND_SITE(v1, 1) JPEGAMD_APPEND_SITE(v2, 2) JPEGAMD_APPEND_SITE(v3, 3) JPEGAMD_APPEND_SITE(v4, 4)
+                     JPEGAMD_APPEND_SITE(v5, 5) JPEGAMD_APPEND_SITE(v6, 6) JPEGAMD_APPEND_SITE(v7, 7)
+                     : [addr] "+v"(addr), [save] "=&s"(save), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]), [v4] "+v"(v[4]),
+                       [v5] "+v"(v[5]), [v6] "+v"(v[6]), [v7] "+v"(v[7])
+                     : [zg] "v"(zg)
+                     : "vcc", "memory");
+    } else {
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     JPEGAMD_APPEND_SITE(v0, 0) JPEGAMD_APPEND_SITE(v1, 1) JPEGAMD_APPEND_SITE(v2, 2) JPEGAMD_APPEND_SITE(v3, 3)
+                     JPEGAMD_APPEND_SITE(v4, 4) JPEGAMD_APPEND_SITE(v5, 5) JPEGAMD_APPEND_SITE(v6, 6) JPEGAMD_APPEND_SITE(v7, 7)
+                     : [addr] "+v"(addr), [save] "=&s"(save), [v0] "+v"(v[0]), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]),
+                       [v4] "+v"(v[4]), [v5] "+v"(v[5]), [v6] "+v"(v[6]), [v7] "+v"(v[7])
+                     : [zg] "v"(zg)
+                     : "vcc", "memory");
+    }
+}
+#undef JPEGAMD_APPEND_SITE
+
 template <bool kTaps>
 __global__ __launch_bounds__(64 * kWavesT) __attribute__((amdgpu_waves_per_eu(JPEGAMD_TILE_WAVES, JPEGAMD_TILE_WAVES)))
 void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSched sch) {
@@ -148,7 +196,8 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     __shared__ float s_qstep[64];
     __shared__ float s_cos[64];
     __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][64];   // exact-order path: the 64 terms of one coefficient
-    __shared__ float s_grp[8];                 // [group][h]: |acc| below this => every site of the group quantises to an unflagged 0
+    __shared__ float s_grp[16];                // [group][h]: |acc| below [0..7] => every site of the group quantises to an unflagged 0;
+                                               // [8..15]: the largest tie threshold of the group's sites (fract(zc) above it => no site is flagged)
     // The tile's centred luma (binary16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
     // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
     // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
@@ -168,7 +217,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
             s_q[t] = make_float2(out.tables->qmul[t], out.tables->qthr[t]);
             s_qstep[t] = out.tables->qstep[t];
             s_cos[t] = kCosFM[t];
-            if (t < 8) s_grp[t] = out.tables->grp_thr[t];
+            if (t < 8) { s_grp[t] = out.tables->grp_thr[t]; s_grp[8 + t] = out.tables->flag_thr[t]; }
         }
     }
     __syncthreads();
@@ -176,10 +225,35 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
     const int h = lane >> 5, b = lane & 31;
-    const float bias = out.tables->bias;
+    float bias;                                 // in a VGPR: v_fma_f32 with three VGPR operands issues in 2 cycles, with an SGPR operand in 4 (profiles/r02_issue_model_forms.txt)
+#if JPEGAMD_BIAS_VGPR
+    asm volatile("v_mov_b32 %0, %1" : "=v"(bias) : "s"(out.tables->bias));
+#else
+    bias = out.tables->bias;
+#endif
     const LumaWeights lw = luma_weights(im.weights);
     const uint32_t luma_kc = 0xFFFF8000u;
     const float2 *sq_lane = &s_q[8 * h];
+#if JPEGAMD_THR_REGS
+    // The lane's group thresholds live in registers: every one read from LDS inside the loop is a round trip the wave waits
+    // for right in front of a wave-wide branch.
+    float zero_thr[4], flag_thr[4];
+    {   // one block: the results are not there before the wait, and the compiler must not touch them in between
+        const uint32_t ga = (uint32_t)(uintptr_t)&s_grp[h];
+        asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:8\n\tds_read_b32 %2, %8 offset:16\n\tds_read_b32 %3, %8 offset:24\n\t"
+                     "ds_read_b32 %4, %8 offset:32\n\tds_read_b32 %5, %8 offset:40\n\tds_read_b32 %6, %8 offset:48\n\tds_read_b32 %7, %8 offset:56\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(zero_thr[0]), "=&v"(zero_thr[1]), "=&v"(zero_thr[2]), "=&v"(zero_thr[3]),
+                       "=&v"(flag_thr[0]), "=&v"(flag_thr[1]), "=&v"(flag_thr[2]), "=&v"(flag_thr[3])
+                     : "v"(ga) : "memory");
+    }
+#define zero_thr(G) zero_thr[G]
+#define flag_thr(G) flag_thr[G]
+#else
+    const float *zthr_lds = &s_grp[h];
+#define zero_thr(G) zthr_lds[2 * (G)]
+#define flag_thr(G) zthr_lds[8 + 2 * (G)]
+#endif
 
     // Persistent waves: tile = first, first + stride, ...  The matrix image is loaded once per workgroup and the
     // NEXT tile's pixel rows are requested as soon as the current ones are converted, so their HBM latency
@@ -267,6 +341,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const bool active = b < nblk, interior = tg.interior;
         int nexact = 0;
         TSTAMP(0);   // loop overhead / geometry
+#if JPEGAMD_TICKET_EARLY == 1
+        const uint32_t ticket_v = ticket();
+#endif
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         f16x8 bfrag[4];
         if (interior) {                        // rows requested one iteration ago, behind the ticket (below)
@@ -322,6 +399,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
 
         TSTAMP(3);   // MFMA
+#if JPEGAMD_TICKET_EARLY == 2
+        const uint32_t ticket_v = ticket();
+#endif
         // ---- 3. quantise with the guard band, one GROUP of 8 sites at a time -----------------------
         // Site s = 16H + r of lane (h, b) holds zigzag position 16 * (s >> 3) + 8 * h + (s & 7): group G = s >> 3
         // covers zigzag 16G .. 16G + 15 across the two lanes of a block.  Every instruction of any wave costs one
@@ -340,7 +420,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 float m = fmaxf(fabsf(JPEGAMD_ACC(8 * G)), fabsf(JPEGAMD_ACC(8 * G + 1)));
 #pragma unroll
                 for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(JPEGAMD_ACC(8 * G + j)));
-                gact[G] = __ballot(m >= s_grp[2 * G + h]) != 0ull;
+                gact[G] = __ballot(m >= zero_thr(G)) != 0ull;
             }
             if (gact[G]) {
                 float fr[8], th[8];
@@ -353,7 +433,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     fr[j] = __builtin_amdgcn_fractf(zc);
                     th[j] = q.y;
                 }
-                flagbits |= shift_in_le8(0u, fr, th) << (8 * G);            // bit j: site 8G + j is within delta of a tie
+                // Flags are rare (0.4 per tile): one min tree over the fractions against the group's largest threshold decides
+                // for the whole wave whether the per-site compares (16 instructions) are needed at all.
+                const float fmin8 = fminf(fminf(__builtin_fminf(fr[0], fminf(fr[1], fr[2])), fminf(fr[3], fminf(fr[4], fr[5]))), fminf(fr[6], fr[7]));
+                if (!JPEGAMD_FLAG_MINTREE || __ballot(fmin8 <= flag_thr(G)) != 0ull)
+                    flagbits |= shift_in_le8(0u, fr, th) << (8 * G);        // bit j: site 8G + j is within delta of a tie
             } else if (kTaps) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) n[8 * G + j] = 0;
@@ -377,7 +461,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // behind the exact-order and count phases).  Round 1 asked one whole iteration earlier, for the tile after next:
         // every wave then sat on a reserved, unstarted tile when its group ran dry, and the last waves of a group
         // finished two tile-times (11 us of 58) after the first (profiles/r02_stamps_interleaved.txt).
+#if !JPEGAMD_TICKET_EARLY
         const uint32_t ticket_v = ticket();
+#endif
         // ---- 4. exact-order recomputation of flagged coefficients ------------------------------
         uint64_t exact_mask = 0;
         unsigned long long fm = __ballot(flagbits != 0u);
@@ -479,6 +565,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll
                 for (int i = 0; i < 6; ++i) raw[s].d[i] = 0u;
         }
+        TSTAMP(8);   // ticket wait + next tile's geometry and row requests
         // ---- 6. append the items (from word 0 of the tile's list) ----
         // Per item: one SDWA add writes the zigzag position into the upper half of the value's own register, one write, one
         // offset increment.  Up to kStageItems items the list is built in LDS (the tile's luma there is dead by now) and leaves
@@ -488,6 +575,42 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const bool staged = t_all <= (uint32_t)kStageItems;
         uint32_t *stage = &s_pix[wave][0];
         if (staged) {
+#if JPEGAMD_APPEND_ASM
+            if (active) {
+                const uint32_t stage_addr = (uint32_t)(uintptr_t)stage;      // LDS byte address (the low 32 bits of the flat one)
+                uint32_t addr = 0;
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    if (!gact[G]) continue;
+                    addr = stage_addr + (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
+                    const uint32_t zg = (uint32_t)(16 * G + 8 * h);
+                    int vv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vv[j] = n[8 * G + j];
+                    if (G == 0) {
+                        // site 0: the DC item (always stored, its flags live in the upper half) in lanes h == 0, zigzag 8 in lanes h == 1
+                        uint32_t first_item = dc_item;
+                        if (h) {
+                            first_item = (uint32_t)n[0];
+                            asm("v_add_u32_sdwa %0, %1, 0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+                                : "+v"(first_item) : "v"(zg));
+                        }
+                        if (h == 0 || n[0] != 0) {
+                            asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(first_item) : "memory");
+                            addr += 4u;
+                        }
+                        append_group_lds<true>(addr, vv, zg);
+                    } else {
+                        append_group_lds<false>(addr, vv, zg);
+                    }
+                }
+                if (eob) {
+                    if (!gact[3]) addr = stage_addr + (blk_base + (starts >> 24)) * 4u;
+                    asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(kItEobValue) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the asm writes are invisible to the compiler's counters
+#else
             if (active) {
                 uint32_t off = 0;
 #pragma unroll
@@ -513,6 +636,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     stage[off] = kItEobValue;
                 }
             }
+#endif
             if (lane == 0 && (t_all & 1u)) stage[t_all] = kItPadValue;  // k_entropy's lanes take two items each: even count per list
         } else {
 #ifdef JPEGAMD_NO_ITEM_STORE           // timing-only build: zero records, the range check drops every item store (stream, waits unchanged)
@@ -573,7 +697,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         if (lane == 0 && out.stamps) {
             unsigned long long *o = out.stamps + (size_t)(blockIdx.x * kWavesT + wave) * 16;
             for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
-            o[8] = st_rt0; o[9] = st_rt1; o[10] = st_rt2; o[11] = st_c2 - st_c1;
+            o[8] = st_rt0; o[9] = st_rt1; o[10] = st_rt2; o[11] = st_c2 - st_c1; o[12] = st_sum[8];
         }
     }
 #endif

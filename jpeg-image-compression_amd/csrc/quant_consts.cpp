@@ -218,6 +218,9 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
                 const double up = 1.0 - (double)mt->bias, dn = (double)mt->bias - (double)mt->qthr[z];
                 t = std::fmin(t, std::fmin(up, dn) / (double)mt->qmul[z]);
             }
+            float fmax = 0.0f;
+            for (int j = 0; j < 8; ++j) fmax = std::fmax(fmax, mt->qthr[16 * g + 8 * h + j]);
+            mt->flag_thr[2 * g + h] = fmax;
             mt->grp_thr[2 * g + h] = (float)(t * (1.0 - 1.0 / 262144.0));
             if ((double)mt->grp_thr[2 * g + h] > t * (1.0 - 1.0 / 524288.0)) mt->grp_thr[2 * g + h] = std::nextafterf(mt->grp_thr[2 * g + h], 0.0f);
         }

@@ -33,17 +33,18 @@ fn.restype = C.c_int32
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 rc = fn(enc._h, buf.ctypes.data, nwaves)
 assert rc == 0, rc
-names = ["loop/geometry", "wait rows + luma", "issue next loads", "mfma", "quantise", "exact fallback", "counts+scans", "appends"]
-tot = buf[:, :8].sum()
-print(f"waves {nwaves}, mean ticks per wave {buf[:, :8].sum(axis=1).mean():.0f} (max {buf[:, :8].sum(axis=1).max()})")
+names = ["loop/geometry", "wait rows + luma", "luma -> LDS", "mfma", "quantise", "exact fallback", "counts+scans", "appends + copy-out", "ticket wait + row requests"]
+ph = np.concatenate([buf[:, :8], buf[:, 12:13]], axis=1)          # phase sums: slots 0..7 and 12 (8..11 hold the real-time stamps)
+tot = ph.sum()
+print(f"waves {nwaves}, mean ticks per wave {ph.sum(axis=1).mean():.0f} (max {ph.sum(axis=1).max()})")
 for i, n in enumerate(names):
-    print(f"  {n:18s} {buf[:, i].mean():10.0f} ticks/wave  {100.0 * buf[:, i].sum() / tot:5.1f} %")
-tw = buf[:, :8].sum(axis=1).astype(np.float64).reshape(-1, 8)          # [workgroup][wave]
+    print(f"  {n:26s} {ph[:, i].mean():10.0f} ticks/wave  {100.0 * ph[:, i].sum() / tot:5.1f} %")
+tw = ph.sum(axis=1).astype(np.float64).reshape(-1, 8)          # [workgroup][wave]
 print(f"per-wave total: mean {tw.mean():.0f}  std {tw.std():.0f}  p50 {np.percentile(tw, 50):.0f}  p90 {np.percentile(tw, 90):.0f}  p99 {np.percentile(tw, 99):.0f}  max {tw.max():.0f}")
 print(f"workgroup means: std {tw.mean(axis=1).std():.0f}  min {tw.mean(axis=1).min():.0f}  max {tw.mean(axis=1).max():.0f};  within-workgroup std (mean) {tw.std(axis=1).mean():.0f}")
 for i, n in enumerate(names):
-    col = buf[:, i].astype(np.float64)
-    print(f"  {n:18s} std {col.std():8.0f}  p99 {np.percentile(col, 99):8.0f}  max {col.max():8.0f}")
+    col = ph[:, i].astype(np.float64)
+    print(f"  {n:26s} std {col.std():8.0f}  p99 {np.percentile(col, 99):8.0f}  max {col.max():8.0f}")
 ex = buf[:, 5].astype(np.float64)
 print("corr(total, exact) =", np.corrcoef(tw.reshape(-1), ex)[0, 1], " corr(total, appends) =", np.corrcoef(tw.reshape(-1), buf[:, 7].astype(np.float64))[0, 1])
 
