@@ -24,7 +24,7 @@ constexpr int kSegBlocks = kTileBlocks * kSegTiles;                  // 256
 constexpr int kMaxBlockBits = 20 + 63 * 27;                          // 1721
 constexpr int kSegCapWords = ((kSegBlocks * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64;   // words reserved per segment
 constexpr int kAFragWords = 2 * 2 * 4 * 64 * 4;                      // [term][chain][kstep][lane] x 8 binary16 = 16 KiB
-constexpr float kMfmaScale = 16384.0f;                               // the A fragments hold kMfmaScale * LUT product
+constexpr float kMfmaScale = 2048.0f;                                // the accumulator chains hold kMfmaScale * LUT sum (hi chain + lo chain)
 
 // Per-tile symbol lists in HBM (k_tile_transform -> k_entropy).  A list holds the tile's items from word 0, in block order
 // then zigzag order; a block's run is: DC item, non-zero AC items, EOB item (kItEobValue) unless zigzag 63 is non-zero.
@@ -44,7 +44,7 @@ constexpr int kTileRecord = kTileItemCap - 4;
 static_assert(kTileBlocks * 65 + 64 <= kTileRecord, "the per-tile record must lie behind the longest list and its read-ahead");
 
 struct MfmaTables {
-    uint32_t afrag[kAFragWords];   // kMfmaScale * LUT-product matrix, 2-way binary16 split (lo, hi), MFMA A-operand order
+    uint32_t afrag[kAFragWords];   // kMfmaScale * LUT-product matrix as two integer-valued binary16 terms (lo 2^-11, hi), MFMA A-operand order
     float qmul[64];                // by zigzag position z: M_z = K / (q * kMfmaScale)  (the MFMA output is kMfmaScale * LUT sum)
     float qthr[64];                // (bias - 0.5) + delta_z
     float qstep[64];               // (float) q, by zigzag position

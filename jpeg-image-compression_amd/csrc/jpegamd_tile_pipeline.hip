@@ -195,6 +195,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     __shared__ float2 s_q[64];                 // (multiplier, threshold) by zigzag position
     __shared__ float s_qstep[64];
     __shared__ float s_cos[64];
+    __shared__ uint32_t s_zz[64];               // zigzag position -> raster index (exact-order path)
     __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][64];   // exact-order path: the 64 terms of one coefficient
     __shared__ float s_grp[16];                // [group][h]: |acc| below [0..7] => every site of the group quantises to an unflagged 0;
                                                // [8..15]: the largest tie threshold of the group's sites (fract(zc) above it => no site is flagged)
@@ -217,6 +218,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
             s_q[t] = make_float2(out.tables->qmul[t], out.tables->qthr[t]);
             s_qstep[t] = out.tables->qstep[t];
             s_cos[t] = kCosFM[t];
+            s_zz[t] = kZZ[t];
             if (t < 8) { s_grp[t] = out.tables->grp_thr[t]; s_grp[8 + t] = out.tables->flag_thr[t]; }
         }
     }
@@ -369,11 +371,16 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 for (int j = 0; j < 8; ++j) ty[(2 * s + h) * 8 + j] = (int8_t)(int)(float)bfrag[s][j];
         }
 
-        // ---- 2. the 64x64 transform on the matrix pipe: small terms first ----------------------
-        f32x16 acc[2];
+        // ---- 2. the 64x64 transform on the matrix pipe ------------------------------------------
+        // The LUT products are split into two INTEGER-valued binary16 terms (hi = round(2^11 K), lo = round(2^22 (K - hi 2^-11)),
+        // stored as lo 2^-11), and each term has its own accumulator chain: with |pixel| <= 128 every product and every partial
+        // sum of a chain is a multiple of its unit below 2^24 units, so the float32 accumulation is EXACT in any order the
+        // matrix pipe may use.  One float add joins the chains (its single rounding is in the guard band).  Round 2's first
+        // kernel ran both terms through one accumulator and had to budget 2 x 16 roundings per MFMA: 2.3 x the reference's
+        // own evaluation error, i.e. three times as many exact-order events (quant_consts.cpp).
+        f32x16 acc[2][2];                      // [term][chain]
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {          // unrolled (a rolled loop paid ~12 scalar/branch slots per term for the C = 0 special case);
-                                               // the A fragments of one term are fetched kAfrBatch at a time so that
+        for (int t = 0; t < 2; ++t) {          // the A fragments of one term are fetched kAfrBatch at a time so that
             const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];     // the MFMAs issue back to back behind ONE wait
 #pragma unroll
             for (int s0 = 0; s0 < 4; s0 += kAfrBatch) {
@@ -387,11 +394,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 for (int i = 0; i < kAfrBatch; ++i)
 #pragma unroll
                     for (int H = 0; H < 2; ++H) {
-                        if (t == 0 && s0 + i == 0) {       // C = 0 as an inline constant: no accumulator clearing
+                        if (s0 + i == 0) {                 // C = 0 as an inline constant: no accumulator clearing
                             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[0], zero, 0, 0, 0);
+                            acc[t][H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[0], zero, 0, 0, 0);
                         } else {
-                            acc[H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[s0 + i], acc[H], 0, 0, 0);
+                            acc[t][H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[s0 + i], acc[t][H], 0, 0, 0);
                         }
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -409,17 +416,22 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // so the kernel is bound by its instruction count, and in photo-like content most tiles have NO non-zero
         // coefficient in the higher groups: one max|acc| test (5 instructions) skips the quantiser, the counts
         // and the appends of such a group (11+ instructions per site).
-#define JPEGAMD_ACC(site) acc[(site) >> 4][(site) & 15]
+#define JPEGAMD_ACC(site) (acc[1][(site) >> 4][(site) & 15] + acc[0][(site) >> 4][(site) & 15])     /* hi chain + lo chain */
         int n[32];
         uint32_t flagbits = 0;                                      // bit s: site s of this lane is within delta of a rounding tie
         bool gact[4];
+        float dc_sum = 0.0f;                                        // kMfmaScale x the block's pixel sum (lanes h == 0), exact
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
             gact[G] = true;
-            if (G > 0) {                                            // |acc| below the group's zero threshold in every lane?
-                float m = fmaxf(fabsf(JPEGAMD_ACC(8 * G)), fabsf(JPEGAMD_ACC(8 * G + 1)));
+            float a8[8];                                            // the group's LUT sums (times kMfmaScale)
 #pragma unroll
-                for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(JPEGAMD_ACC(8 * G + j)));
+            for (int j = 0; j < 8; ++j) a8[j] = JPEGAMD_ACC(8 * G + j);
+            if (G == 0) dc_sum = a8[0];
+            if (G > 0) {                                            // |sum| below the group's zero threshold in every lane?
+                float m = fmaxf(fabsf(a8[0]), fabsf(a8[1]));
+#pragma unroll
+                for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(a8[j]));
                 gact[G] = __ballot(m >= zero_thr(G)) != 0ull;
             }
             if (gact[G]) {
@@ -428,7 +440,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 for (int j = 0; j < 8; ++j) {
                     const int st = 8 * G + j;
                     const float2 q = sq_lane[16 * G + j];
-                    const float zc = fmaf(JPEGAMD_ACC(st), q.x, bias);      // z + 0.5 + delta
+                    const float zc = fmaf(a8[j], q.x, bias);                // z + 0.5 + delta
                     n[st] = floor_to_int(zc);
                     fr[j] = __builtin_amdgcn_fractf(zc);
                     th[j] = q.y;
@@ -449,7 +461,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         {
             const bool dcflag = (h == 0) && (flagbits & 1u);
             if (__ballot(dcflag) != 0ull) {
-                const int dc_exact = ref_quantise(__fmul_rn(ref_scale(0, 0), __fmul_rn(acc[0][0], 1.0f / kMfmaScale)), s_qstep[0]);   // the scaled sum is exact, and so is 2^-14 of it
+                const int dc_exact = ref_quantise(__fmul_rn(ref_scale(0, 0), __fmul_rn(dc_sum, 1.0f / kMfmaScale)), s_qstep[0]);   // the scaled sum is exact, and so is 2^-11 of it
                 if (dcflag) n[0] = dc_exact;
             }
             if (h == 0) flagbits &= ~1u;
@@ -468,6 +480,12 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         uint64_t exact_mask = 0;
         unsigned long long fm = __ballot(flagbits != 0u);
         if (__builtin_expect(fm != 0ull, 0)) {
+            // Everything this rare path derives from the lane number is computed HERE, from a lane id the compiler cannot trace
+            // to the kernel's own: as loop invariants of the tile loop those values were spilled to scratch and reloaded for
+            // every event (and the zigzag table was a global load): three memory round trips per event behind a vmcnt(0).
+            int el;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
+            const uint32_t *pix_lane = &s_pix[wave][(el >> 3) * 132 + ((el & 7) >> 1)];
             while (fm) {
                 const int fl = __ffsll((long long)fm) - 1;
                 fm &= fm - 1;
@@ -476,18 +494,18 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     const int st = __ffs((int)bits) - 1;
                     bits &= bits - 1;
                     const int z = 16 * (st >> 3) + 8 * (fl >> 5) + (st & 7);
-                    const int k = kZZ[z], u = k >> 3, v = k & 7;
-                    const uint32_t pw = s_pix[wave][(lane >> 3) * 132 + (fl & 31) * 4 + ((lane & 7) >> 1)];
-                    const float pix = (float)__builtin_bit_cast(_Float16, (uint16_t)((lane & 1) ? pw >> 16 : pw));
-                    const float coef = exact_coef_float_lds(pix, u, v, s_cos, s_terms[wave], lane);
+                    const int k = __builtin_amdgcn_readfirstlane((int)s_zz[z]), u = k >> 3, v = k & 7;
+                    const uint32_t pw = pix_lane[(fl & 31) * 4];
+                    const float pix = (float)__builtin_bit_cast(_Float16, (uint16_t)((el & 1) ? pw >> 16 : pw));
+                    const float coef = exact_coef_float_lds(pix, u, v, s_cos, s_terms[wave], el);
                     const int val = ref_quantise(coef, s_qstep[z]);
                     ++nexact;
-                    if (kTaps && lane == fl) exact_mask |= 1ull << k;
+                    if (kTaps && el == fl) exact_mask |= 1ull << k;
                     const int jj = st & 7;
                     switch (st >> 3) {                              // uniform: only the 8 registers of the site's group are touched
 #define JPEGAMD_PUT(G)                                                                                    \
     case G:                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) n[8 * G + j] = (j == jj && lane == fl) ? val : n[8 * G + j]; \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) n[8 * G + j] = (j == jj && el == fl) ? val : n[8 * G + j]; \
         break;
                         JPEGAMD_PUT(0) JPEGAMD_PUT(1) JPEGAMD_PUT(2) JPEGAMD_PUT(3)
 #undef JPEGAMD_PUT
@@ -565,7 +583,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll
                 for (int i = 0; i < 6; ++i) raw[s].d[i] = 0u;
         }
-        TSTAMP(8);   // ticket wait + next tile's geometry and row requests
         // ---- 6. append the items (from word 0 of the tile's list) ----
         // Per item: one SDWA add writes the zigzag position into the upper half of the value's own register, one write, one
         // offset increment.  Up to kStageItems items the list is built in LDS (the tile's luma there is dead by now) and leaves
@@ -697,7 +714,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         if (lane == 0 && out.stamps) {
             unsigned long long *o = out.stamps + (size_t)(blockIdx.x * kWavesT + wave) * 16;
             for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
-            o[8] = st_rt0; o[9] = st_rt1; o[10] = st_rt2; o[11] = st_c2 - st_c1; o[12] = st_sum[8];
+            o[8] = st_rt0; o[9] = st_rt1; o[10] = st_rt2; o[11] = st_c2 - st_c1;
         }
     }
 #endif

@@ -156,21 +156,24 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
     uint16_t *af = reinterpret_cast<uint16_t *>(mt->afrag);
     double delta_z[64];
     double dmax = 0;
+    bool split_ok = true;
     const double S = (double)kMfmaScale;
     for (int z = 0; z < 64; ++z) {
         const int k = kZigzagHost[z], u = k >> 3, v = k & 7;
-        double kmat[64], term[2][64], split_res = 0;       // terms in units of Kmat (i.e. already divided by the scale)
+        double kmat[64], term[2][64], split_res = 0, hi_units = 0, lo_units = 0;     // terms in units of Kmat
         for (int x = 0; x < 8; ++x)
             for (int y = 0; y < 8; ++y) {
                 const int p = x * 8 + y;
                 kmat[p] = (double)kCosLut[x][u] * (double)kCosLut[y][v];
-                const uint16_t hi = to_f16(kmat[p] * S);
-                const double r1 = kmat[p] * S - from_f16(hi);
-                const uint16_t lo = to_f16(r1);
-                term[0][p] = from_f16(lo) / S; term[1][p] = from_f16(hi) / S;
-                const double res_kept = std::fabs(kmat[p] - (term[0][p] + term[1][p]));
-                const double res_flushed = ((lo & 0x7C00u) == 0) ? std::fabs(kmat[p] - term[1][p]) : res_kept;
-                split_res += std::fmax(res_kept, res_flushed);
+                // hi = round(2^11 K) (|hi| <= 2048: an integer binary16 holds exactly), lo = round(2^22 (K - hi 2^-11)) (|lo| <= 1024),
+                // stored as lo 2^-11 (a multiple of 2^-11 with an 11-bit numerator: exact as well)
+                const double hi_i = std::nearbyint(kmat[p] * 2048.0);
+                const double lo_i = std::nearbyint((kmat[p] - hi_i / 2048.0) * 4194304.0);
+                const uint16_t hi = to_f16(hi_i), lo = to_f16(lo_i / 2048.0);
+                if (from_f16(hi) != hi_i || from_f16(lo) != lo_i / 2048.0 || std::fabs(hi_i) > 2048.0 || std::fabs(lo_i) > 1024.0) split_ok = false;
+                term[0][p] = lo_i / 4194304.0; term[1][p] = hi_i / 2048.0;
+                split_res += std::fabs(kmat[p] - (term[0][p] + term[1][p]));
+                hi_units += std::fabs(hi_i); lo_units += std::fabs(lo_i);
                 // scatter into the A-operand order: term t, chain H, matrix row R, k-step s, lane (hk, R), element j;
                 // lane half h = (z >> 3) & 1 holds z = 16G + 8h + j at site 8G + j = 16H + r
                 const int site = 8 * (z >> 4) + (z & 7);
@@ -185,15 +188,11 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
         double wsum = 0, run = 0, adds = 0;
         for (int j = 0; j < 64; ++j) { const double w = std::fabs(kmat[j]); wsum += w; run += w; if (j >= 1) adds += run; }
         const double e_ref = (2.0 * kU * kPmax * wsum + kU * kPmax * adds) * 1.001;
-        // accumulation bound, MFMA order: terms lo, hi; k-steps 0..3 inside each (in Kmat units: the scale cancels)
-        double acc = 0, e_mfma = 0;
-        for (int t = 0; t < 2; ++t)
-            for (int s = 0; s < 4; ++s) {
-                double sm = 0;
-                for (int j = 0; j < 16; ++j) sm += std::fabs(term[t][16 * s + j]) * kPmax;
-                e_mfma += 2.0 * 16.0 * kU * (acc + sm) * 1.0001;
-                acc += sm;
-            }
+        // Each chain is exact when every partial sum stays below 2^24 of its units (hi: 1, lo: 2^-11 of the hi unit) whatever the
+        // summation order: |pixel| * sum |term| bounds them all.  What is left of the matrix pipe is the ONE rounding of the add
+        // that joins the chains, relative to |S| <= kPmax * wsum.
+        if (kPmax * hi_units > 16777216.0 || kPmax * lo_units > 16777216.0) split_ok = false;      // (integers up to 2^24 inclusive are float32 values)
+        const double e_mfma = kU * kPmax * wsum * 1.0001;
         const float cu = u == 0 ? 0.707107f : 1.0f, cv = v == 0 ? 0.707107f : 1.0f;
         const double K = (double)((0.25f * cu) * cv);
         const double q = (double)table[k];
@@ -208,6 +207,8 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
     mt->bias = (float)(0.5 + dmax * 1.001 + 1.0e-7);
     const double db = (double)mt->bias - 0.5;
     for (int z = 0; z < 64; ++z) mt->qthr[z] = (float)(db + delta_z[z] * 1.001 + 1.0e-7);
+    if (!split_ok)                                          // cannot happen with the reference's LUT; if it did, EVERY coefficient takes the exact-order path
+        for (int z = 0; z < 64; ++z) mt->qthr[z] = 2.0f;
     // zero threshold of a group: qthr < fl(a * qmul + bias) < 1 (i.e. floor = 0, not flagged) for every |a| below it;
     // the 2^-18 relative margin covers the single rounding of the kernel's fma
     for (int g = 0; g < 4; ++g)

@@ -119,7 +119,8 @@ def test_mfma_constants_are_on_the_safe_side(jpegamd, oracle):
             assert np.float64(c["qthr"][z]) >= db + c["delta"][k]
             u, v = divmod(k, 8)
             kk = np.float32(np.float32(np.float32(0.25) * (np.float32(0.707107) if u == 0 else np.float32(1))) * (np.float32(0.707107) if v == 0 else np.float32(1)))
-            assert abs(float(c["qmul"][z]) * 16384.0 - float(kk) / float(table[k])) <= 1e-7 * float(kk)     # kMfmaScale = 2^14
+            assert abs(float(c["qmul"][z]) * 2048.0 - float(kk) / float(table[k])) <= 1e-7 * float(kk)     # kMfmaScale = 2^11
+            assert float(c["qthr"][z]) < 0.01                                # (2.0 would mean: the integer split failed, everything is flagged)
         assert 1e-5 < c["delta"][1:].max() < 5e-3
 
 
@@ -145,56 +146,62 @@ def test_group_zero_thresholds_are_safe(jpegamd):
 
 
 def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
-    """The matrix-pipe path on the CPU: 2^14 x LUT-product matrix split into two binary16 terms, float32 accumulation in
-    three different orders (the hardware's order inside an MFMA is not specified; the bound is order-free), the kernel's fma
-    and flag test.  A coefficient the guard does NOT flag must equal the reference's quantised value, and the
-    observed |z_fast - z_ref| must stay below delta (random, flat, extreme and basis-aligned blocks)."""
+    """The matrix-pipe path on the CPU: the LUT-product matrix as two integer-valued binary16 terms (hi = round(2^11 K),
+    lo = round(2^22 (K - hi 2^-11)) stored as lo 2^-11), one accumulator chain per term, float32 accumulation in three
+    different orders (the hardware's order inside an MFMA is not specified).  Every chain must come out EXACT in every
+    order; then one float32 add joins them, followed by the kernel's fma and flag test.  A coefficient the guard does NOT
+    flag must equal the reference's quantised value, and the observed |z_fast - z_ref| must stay below delta (random, flat,
+    extreme and basis-aligned blocks)."""
     f32, f64 = np.float32, np.float64
     zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
     lut = jpegamd.cos_lut()                                        # COS_LUT[x][u] as compiled into the kernels
-    SCALE = 16384.0                                                # kMfmaScale
-
-    def f16(x):                                                    # round-to-nearest-even to binary16, as float64 values
-        return np.asarray(x, f64).astype(np.float16).astype(f64)
+    SCALE = 2048.0                                                 # kMfmaScale
 
     K = np.zeros((64, 64))
     for k in range(64):
         u, v = divmod(k, 8)
         K[k] = np.outer(lut[:, u].astype(f64), lut[:, v].astype(f64)).reshape(64)     # K[k][x*8+y] = LUT[x][u] * LUT[y][v]
-    hi = f16(K * SCALE); lo = f16(K * SCALE - hi)
-    assert np.abs(hi).max() <= 16384.0 and np.abs(K * SCALE - hi - lo).max() < 2.0 ** -9
-    terms = [lo, hi]                                               # small term first, like the kernel
+    hi = np.rint(K * SCALE); lo = np.rint((K - hi / SCALE) * 4194304.0) / SCALE
+    for t in (hi, lo):                                             # both terms are binary16 values
+        assert np.array_equal(t.astype(np.float16).astype(f64), t)
+    assert np.abs(hi).max() <= 2048 and np.abs(lo * SCALE).max() <= 1024 and np.abs(K * SCALE - hi - lo).max() <= 2.0 ** -12
+    terms = [lo, hi]
     rng = np.random.default_rng(11)
     blocks = [rng.integers(-128, 128, 64) for _ in range(150)] + [np.full(64, v) for v in (-128, 127, 3, -77)]
-    blocks += [np.where(K[k] >= 0, 127, -128) for k in (1, 9, 27, 63)] + [rng.integers(-4, 5, 64) + 100 for _ in range(20)]
+    blocks += [np.where(K[k] >= 0, 127, -128) for k in (1, 9, 27, 63)] + [np.where(K[k] >= 0, -128, -128) for k in (0,)]
+    blocks += [rng.integers(-4, 5, 64) + 100 for _ in range(20)]
     P = np.array(blocks, dtype=np.int64)
     ref = oracle.dct_blocks(P.reshape(-1, 8, 8).astype(np.int8)).reshape(-1, 64)
 
-    def accumulate(order):
+    def chain(t, order):
         acc = np.zeros((len(P), 64), f32)
-        for t in terms:
-            prod = (t[None, :, :] * P[:, None, :].astype(f64)).astype(f32)          # exact in float32: 11 x 8 significant bits
-            for s in range(4):
-                idx = list(range(16 * s, 16 * s + 16))
-                if order == "reverse":
-                    idx = idx[::-1]
-                if order == "pairwise":
-                    part = prod[:, :, idx]
-                    while part.shape[2] > 1:
-                        part = (part[:, :, 0::2] + part[:, :, 1::2]).astype(f32)
-                    acc = (acc + part[:, :, 0]).astype(f32)
-                else:
-                    for i in idx:
-                        acc = (acc + prod[:, :, i]).astype(f32)
+        prod = (t[None, :, :] * P[:, None, :].astype(f64)).astype(f32)              # exact in float32: 11 x 8 significant bits
+        assert np.array_equal(prod.astype(f64), t[None, :, :] * P[:, None, :].astype(f64))
+        for s in range(4):
+            idx = list(range(16 * s, 16 * s + 16))
+            if order == "reverse":
+                idx = idx[::-1]
+            if order == "pairwise":
+                part = prod[:, :, idx]
+                while part.shape[2] > 1:
+                    part = (part[:, :, 0::2] + part[:, :, 1::2]).astype(f32)
+                acc = (acc + part[:, :, 0]).astype(f32)
+            else:
+                for i in idx:
+                    acc = (acc + prod[:, :, i]).astype(f32)
         return acc
 
+    exact = [(P[:, None, :].astype(f64) * t[None, :, :]).sum(axis=2) for t in terms]
     for q in (50, 90):
         c = jpegamd.mfma_consts(q)
         table = oracle.quant_table(q).astype(f32)
         bias = f32(c["bias"])
         for order in ("forward", "reverse", "pairwise"):
-            acc = accumulate(order)
+            chains = [chain(t, order) for t in terms]
+            for got, want in zip(chains, exact):
+                assert np.array_equal(got.astype(f64), want), order                       # exact, whatever the order
+            acc = (chains[1] + chains[0]).astype(f32)                                     # the kernel's one add
             unflagged = 0
             for z in range(64):
                 k = zz[z]

@@ -33,8 +33,8 @@ fn.restype = C.c_int32
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 rc = fn(enc._h, buf.ctypes.data, nwaves)
 assert rc == 0, rc
-names = ["loop/geometry", "wait rows + luma", "luma -> LDS", "mfma", "quantise", "exact fallback", "counts+scans", "appends + copy-out", "ticket wait + row requests"]
-ph = np.concatenate([buf[:, :8], buf[:, 12:13]], axis=1)          # phase sums: slots 0..7 and 12 (8..11 hold the real-time stamps)
+names = ["loop/geometry", "wait rows + luma", "luma -> LDS", "mfma", "quantise", "exact fallback", "counts+scans", "ticket, row requests, appends, copy-out"]
+ph = buf[:, :8]                                                    # phase sums: slots 0..7 (8..11 hold the real-time stamps)
 tot = ph.sum()
 print(f"waves {nwaves}, mean ticks per wave {ph.sum(axis=1).mean():.0f} (max {ph.sum(axis=1).max()})")
 for i, n in enumerate(names):
@@ -67,3 +67,9 @@ for x in range(8):
     m = (blk % 8) == x
     print(f"  xcd-slot {x}: clock {clk[m].mean():.3f} GHz  waves end mean {end[m].mean():.2f} max {end[m].max():.2f} us")
 print(f"idle SIMD-time at the end: {(end.max() - end).mean():.2f} us per wave of {end.max():.2f} ({100 * (end.max() - end).mean() / end.max():.1f} %)")
+
+hist, edges = np.histogram(end, bins=np.arange(np.floor(end.min()), np.ceil(end.max()) + 1.0, 1.0))
+print("waves finishing per microsecond:", " ".join(f"{int(e)}:{c}" for e, c in zip(edges[:-1], hist)))
+busy = np.array([(end > t).sum() for t in np.arange(0.0, end.max(), 1.0)])
+print("waves still running at t (us):", " ".join(f"{int(t)}:{b}" for t, b in zip(np.arange(0.0, end.max(), 1.0), busy) if t >= end.min() - 2))
+np.save(str(ROOT / "gpurun_out" / "stamps" / (os.path.basename(os.environ.get("JPEGAMD_LIB", "default")) + ".npy")), buf)
