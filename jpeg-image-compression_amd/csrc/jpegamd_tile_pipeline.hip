@@ -577,11 +577,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // exactly kCopyStores stores close the iteration (the compiler then waits for vmcnt(kCopyStores), not 0).
         if (nxt < cur_hi && tg_next.interior) {
             request_rows(tg_next, raw);
-        } else {                               // (defined on every path: else the old rows stay live through the whole iteration)
-#pragma unroll
+        } else {                               // (defined on every path -- by an empty asm, i.e. no instruction: else the old rows stay
+#pragma unroll                                 //  live through the whole iteration, and zeroing them was hoisted in front of the branch)
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 6; ++i) raw[s].d[i] = 0u;
+                for (int i = 0; i < 6; ++i) asm volatile("" : "=v"(raw[s].d[i]));
         }
         // ---- 6. append the items (from word 0 of the tile's list) ----
         // Per item: one SDWA add writes the zigzag position into the upper half of the value's own register, one write, one
