@@ -47,7 +47,7 @@ sys.path.insert(0, str(ROOT / "jpeg-image-compression_amd" / "python"))
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-ROTATE = 3                     # image8192: rotating inputs per rank
+ROTATE = int(os.environ.get("JPEGAMD_BENCH_ROTATE", "3"))   # image8192: rotating inputs per rank (1 = experiment: the input stays in the 256 MB Infinity Cache)
 BATCH_PER_RANK = 8             # batch4096: images per rank per step
 
 

@@ -136,6 +136,9 @@ constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket count
 #ifndef JPEGAMD_APPEND_ASM
 #define JPEGAMD_APPEND_ASM 1
 #endif
+#ifndef JPEGAMD_PREFETCH_EARLY
+#define JPEGAMD_PREFETCH_EARLY 0
+#endif
 #ifndef JPEGAMD_COPY_STORES
 #define JPEGAMD_COPY_STORES 4
 #endif
@@ -327,7 +330,8 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
     };
     RawRow raw[4];
-    TileGeo tg = geo(first < cur_hi ? to_tile(first) : im.tile_begin);
+    int tile = first < cur_hi ? to_tile(first) : im.tile_begin;     // picture tile of the iteration (carried: to_tile() once per tile)
+    TileGeo tg = geo(tile);
     if (first < cur_hi && tg.interior) request_rows(tg, raw);
 #ifdef JPEGAMD_STAMPS
     unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
@@ -337,7 +341,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 
 #pragma unroll 1
     for (int li = first; li < cur_hi;) {
-        const int tile = to_tile(li);
         const int by = tg.by, nblk = tg.nblk, bx = tg.bx;
         const int py0 = by * 8, px0 = bx * 8;
         const bool active = b < nblk, interior = tg.interior;
@@ -468,6 +471,35 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
         if (!active) flagbits = 0u;
         TSTAMP(4);   // quantise
+#if JPEGAMD_PREFETCH_EARLY       // ticket collected and the next tile's rows requested HERE: in flight behind the exact-order, count and append phases
+        int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
+#if JPEGAMD_TILE_STEAL
+        // Own group dry: draw from a partner group's counter (its waves cannot tell).  The ticket is waited for here, once or
+        // twice per wave at the very end of its work; a failed draw ends the wave.
+        while (nxt >= cur_hi && steal_level < JPEGAMD_TILE_STEAL && (1 << steal_level) < groups) {
+            cur_grp = grp ^ (1 << steal_level);
+            ++steal_level;
+            cur_hi = tiles_of(cur_grp);
+            cur_waves = waves_of(cur_grp);
+            ctr = out.tile_ctr + cur_grp * 32;
+            nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket());
+        }
+#endif
+        TileGeo tg_next = tg;
+        int tile_next = tile;
+        if (nxt < cur_hi) { tile_next = to_tile(nxt); tg_next = geo(tile_next); }
+        // The next tile's pixel rows: 8 loads, in flight behind the appends.  vmcnt retires in issue order, so the wait at
+        // the top of the loop must not have to count a VARYING number of younger stores: whatever path the appends take,
+        // exactly kCopyStores stores close the iteration (the compiler then waits for vmcnt(kCopyStores), not 0).
+        if (nxt < cur_hi && tg_next.interior) {
+            request_rows(tg_next, raw);
+        } else {                               // (defined on every path -- by an empty asm, i.e. no instruction: else the old rows stay
+#pragma unroll                                 //  live through the whole iteration, and zeroing them was hoisted in front of the branch)
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) asm volatile("" : "=v"(raw[s].d[i]));
+        }
+#endif
 
         // The ticket for this wave's NEXT tile is requested here and collected before the appends (its latency hides
         // behind the exact-order and count phases).  Round 1 asked one whole iteration earlier, for the tile after next:
@@ -557,6 +589,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // The ticket requested at the top of the iteration is collected here, BEFORE the item stores are issued:
         // the wait for it then covers no younger memory operation (built with the atomic optimizer off -- its
         // expansion reads the result back, and waits for vmcnt(0), right behind the atomic).
+#if !JPEGAMD_PREFETCH_EARLY
         int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
 #if JPEGAMD_TILE_STEAL
         // Own group dry: draw from a partner group's counter (its waves cannot tell).  The ticket is waited for here, once or
@@ -571,7 +604,8 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
 #endif
         TileGeo tg_next = tg;
-        if (nxt < cur_hi) tg_next = geo(to_tile(nxt));
+        int tile_next = tile;
+        if (nxt < cur_hi) { tile_next = to_tile(nxt); tg_next = geo(tile_next); }
         // The next tile's pixel rows: 8 loads, in flight behind the appends.  vmcnt retires in issue order, so the wait at
         // the top of the loop must not have to count a VARYING number of younger stores: whatever path the appends take,
         // exactly kCopyStores stores close the iteration (the compiler then waits for vmcnt(kCopyStores), not 0).
@@ -583,6 +617,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll
                 for (int i = 0; i < 6; ++i) asm volatile("" : "=v"(raw[s].d[i]));
         }
+#endif
         // ---- 6. append the items (from word 0 of the tile's list) ----
         // Per item: one SDWA add writes the zigzag position into the upper half of the value's own register, one write, one
         // offset increment.  Up to kStageItems items the list is built in LDS (the tile's luma there is dead by now) and leaves
@@ -705,6 +740,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #undef JPEGAMD_ACC
         TSTAMP(7);   // appends
         li = nxt;
+        tile = tile_next;
         tg = tg_next;
     }
 #ifdef JPEGAMD_STAMPS

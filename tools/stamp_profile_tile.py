@@ -15,7 +15,8 @@ import torch
 import jpegamd
 
 w = h = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-bmp = jpegamd.synth_bmp(w, h, 1000, 0, 0)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bmp = jpegamd.synth_bmp(w, h, seed, 0, 0)
 img, off = jpegamd.parse_bmp(bmp)
 px = torch.frombuffer(bytearray(bmp[off:off + img.row_stride * h]), dtype=torch.uint8).cuda()
 enc = jpegamd.Encoder(w, h)
