@@ -24,7 +24,8 @@ collected at rank 0 with one asynchronous RCCL gather per `--gather-every` image
 Extra objects on the JSON line:
   "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes (BMP rows read + JFIF bytes
                   written, per image) / SUM of the kernels' durations / 8 TB/s.  Durations are HIP-event timed inside
-                  this run through the C-ABI's event ring, on the stream the kernels are launched on; with several
+                  this run through the C-ABI's event ring: every kernel is launched with its own begin / end events
+                  on the stream it runs on (a kernel's own duration, as a kernel trace shows it); with several
                   streams they come from a single-stream pass right after the timed region (kernels of different images
                   overlap in the timed region).  `dominant_frac` is the same bytes over k_tile_transform alone,
                   `hbm_read_frac` the read bytes alone over the sum.
@@ -324,9 +325,10 @@ def main():
     first_timed = W * ips
     ov_tr, ov_en, ov_pk, ov_tot = mean_profile([(e, len([n for n in range(first_timed, first_timed + n_timed) if n % nstreams == si]))
                                                  for si, e in enumerate(encs)])
-    # Kernel durations for the roofline: with several streams the kernels of different images overlap in the
-    # timed region, so an event pair no longer measures one kernel's own duration.  A short single-stream pass
-    # over the same inputs gives each kernel alone (this is what rocprofv3 --stats sees for `bench.py --streams 1`).
+    # Kernel durations for the roofline.  The library launches every kernel with its own begin / end events
+    # (hipExtLaunchKernelGGL), so a duration is the kernel's own, as in a kernel trace -- but with several streams the
+    # kernels of different images share the GPU in the timed region and stretch.  A short single-stream pass over the
+    # same inputs gives each kernel alone (this is what rocprofv3 --stats sees for `bench.py --streams 1`).
     if nstreams > 1:
         P = min(n_timed, 60)
         encs[0].set_profiling(P)

@@ -84,10 +84,12 @@ typedef struct JpegAmdStats {
     uint64_t entropy_bits;      /* unstuffed entropy-coded bits */
     uint64_t stuffed_bytes;     /* number of 0x00 bytes inserted after 0xFF */
     uint64_t exact_fallbacks;   /* coefficients recomputed in the reference's float order */
-    uint64_t ns_transform;      /* luma + DCT + quantisation + zigzag + symbol lists (k_tile_transform, or the fused kernel) */
-    uint64_t ns_entropy;        /* run/size symbols -> Huffman bit strings per segment (k_entropy; 0 when fused) */
-    uint64_t ns_pack;           /* bit / stuffing offsets, stitch, 0xFF stuffing, container (k_fin_count + k_fin_write) */
-    uint64_t ns_total;
+    /* With profiling on (jpegamd_encoder_set_profiling) every kernel is launched with its own begin / end events
+       (hipExtLaunchKernelGGL): the three figures are the kernels' OWN durations, what a kernel trace shows. */
+    uint64_t ns_transform;      /* k_tile_transform: luma + DCT + quantisation + zigzag + symbol lists */
+    uint64_t ns_entropy;        /* k_entropy: run/size symbols -> Huffman bit strings per segment */
+    uint64_t ns_pack;           /* k_finalize: bit / stuffing offsets, stitch, 0xFF stuffing, container */
+    uint64_t ns_total;          /* begin of the first kernel .. end of the last: the three durations plus the launch gaps between them */
 } JpegAmdStats;
 
 typedef struct JpegAmdEncoder JpegAmdEncoder;   /* opaque; owns device scratch */

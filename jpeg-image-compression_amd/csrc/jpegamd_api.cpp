@@ -48,7 +48,7 @@ struct JpegAmdEncoder {
     int prefix_w = -1, prefix_h = -1, prefix_q = -1;
     // profiling: a ring of event quadruples so callers can time many async encodes and read
     // the per-kernel durations after ONE synchronisation
-    struct EventSet { hipEvent_t ev[4]; };
+    struct EventSet { hipEvent_t ev[6]; };     // begin / end of k_tile_transform, k_entropy, k_finalize (the kernels' own timestamps)
     std::vector<EventSet> ring;
     uint64_t calls = 0;          // encodes enqueued since profiling was (re)enabled
     int last_slot = -1;
@@ -204,9 +204,9 @@ static int32_t read_slot(JpegAmdEncoder *e, int slot, JpegAmdStats *stats) {
     hipEvent_t *ev = e->ring[(size_t)slot].ev;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); stats->ns_transform = (uint64_t)((double)ms * 1e6);
-    HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); stats->ns_entropy = (uint64_t)((double)ms * 1e6);
-    HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ns_pack = (uint64_t)((double)ms * 1e6);
-    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[3])); stats->ns_total = (uint64_t)((double)ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ns_entropy = (uint64_t)((double)ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ns_pack = (uint64_t)((double)ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); stats->ns_total = (uint64_t)((double)ms * 1e6);     // first begin .. last end: includes the launch gaps
     return JPEGAMD_OK;
 }
 
@@ -267,7 +267,7 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
 
 // k_tile_transform, then k_entropy; `mid` (optional) is recorded between the two.
 static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
-                                        void *stream, hipEvent_t mid = nullptr) {
+                                        void *stream, hipEvent_t *ev = nullptr /*4: begin/end of the two kernels*/) {
     TransformOutM to;
     std::memset(&to, 0, sizeof(to));
     to.tables = e->tables_dev; to.stamps = e->stamps_dev;
@@ -277,20 +277,19 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     // i % 2 and zeroes the other one for launch i + 1.
     to.tile_ctr = e->tile_ctr + (e->ctr_set ? 64 * 32 : 0);
     to.tile_ctr_next = e->tile_ctr + (e->ctr_set ? 0 : 64 * 32);
-    if (int err = launch_tile_transform(im, to, taps, stream)) return err;
+    if (int err = launch_tile_transform(im, to, taps, stream, (ev && !taps) ? (void *const *)ev : nullptr)) return err;
     if (im.tile_end > im.tile_begin) e->ctr_set ^= 1;      // (an empty range launches nothing)
-    if (mid) (void)hipEventRecord(mid, (hipStream_t)stream);
     EntropyArgs ea;
     std::memset(&ea, 0, sizeof(ea));
     ea.tile_items = e->tile_items;
     ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
     ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
     ea.seg = e->seg;
-    return launch_entropy(ea, stream);
+    return launch_entropy(ea, stream, ev ? (void *const *)(ev + 2) : nullptr);
 }
 
 static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, uint64_t out_capacity, uint64_t *out_size_dev,
-                        int32_t with_container, hipStream_t stream) {
+                        int32_t with_container, hipStream_t stream, hipEvent_t *ev = nullptr) {
     FinalizeArgs fa;
     std::memset(&fa, 0, sizeof(fa));
     fa.seg = e->seg;
@@ -298,7 +297,7 @@ static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, u
     fa.out = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size = out_size_dev; fa.stats = e->stats_dev;
     fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
     fa.write_eoi = with_container ? 1 : 0;
-    return launch_finalize(fa, stream);
+    return launch_finalize(fa, stream, (void *const *)ev);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -409,12 +408,9 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         e->last_slot = (int)(e->calls % e->ring.size());
         ev = e->ring[(size_t)e->last_slot].ev;
         ++e->calls;
-        HIP_TRY(hipEventRecord(ev[0], stream));
     }
-    if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, timed ? ev[1] : nullptr)) return JPEGAMD_ERR_HIP;
-    if (timed) HIP_TRY(hipEventRecord(ev[2], stream));
-    if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
-    if (timed) HIP_TRY(hipEventRecord(ev[3], stream));
+    if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+    if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
     e->last_stream = stream;
     e->pending = true;

@@ -15,6 +15,7 @@
 // When the window is written out (once, for ordinary segments) the wave also counts, for each of the 8 byte phases the
 // segment's first bit may end up at, the 0xFF bytes that lie wholly inside the segment: the finalize kernel then knows
 // every stuffing offset from per-segment numbers alone and the separate counting kernel of round 1 is gone.
+#include <hip/hip_ext.h>
 #include "jpegamd_device.h"
 
 namespace jpegamd {
@@ -327,9 +328,11 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     if (lane < 8) a.seg.ffin[(size_t)seg * 8 + lane] = (uint16_t)min(mine, 65535u);
 }
 
-int launch_entropy(const EntropyArgs &a, void *stream) {
+int launch_entropy(const EntropyArgs &a, void *stream, void *const *ev) {
     if (a.seg_end <= a.seg_begin) return 0;
-    hipLaunchKernelGGL(k_entropy, dim3((a.seg_end - a.seg_begin + kWavesE - 1) / kWavesE), dim3(64 * kWavesE), 0, (hipStream_t)stream, a);
+    const dim3 grid((a.seg_end - a.seg_begin + kWavesE - 1) / kWavesE), block(64 * kWavesE);
+    if (ev) hipExtLaunchKernelGGL(k_entropy, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
+    else hipLaunchKernelGGL(k_entropy, grid, block, 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

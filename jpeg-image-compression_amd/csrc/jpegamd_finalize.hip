@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <hip/hip_ext.h>
 #include "jpegamd_device.h"
 
 namespace jpegamd {
@@ -234,9 +235,10 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     }
 }
 
-int launch_finalize(const FinalizeArgs &a, void *stream) {
+int launch_finalize(const FinalizeArgs &a, void *stream, void *const *ev) {
     if (a.num_chunks <= 0) return 0;
-    hipLaunchKernelGGL(k_finalize, dim3(a.num_chunks), dim3(64 * kFinWaves), 0, (hipStream_t)stream, a);
+    if (ev) hipExtLaunchKernelGGL(k_finalize, dim3(a.num_chunks), dim3(64 * kFinWaves), 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
+    else hipLaunchKernelGGL(k_finalize, dim3(a.num_chunks), dim3(64 * kFinWaves), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

@@ -95,7 +95,9 @@ struct TransformOutM {
     int16_t *tap_zz;
     uint64_t *tap_mask;
 };
-int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream);
+// `ev` (optional): two hipEvent_t that receive the kernel's OWN begin / end timestamps (hipExtLaunchKernelGGL), i.e. what a
+// kernel trace reports as its duration -- an event recorded in front of a launch also sees the dispatch latency.
+int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream, void *const *ev = nullptr);
 
 struct EntropyArgs {            // k_entropy: per-tile symbol lists -> per-segment bit strings
     const uint32_t *tile_items;
@@ -104,7 +106,7 @@ struct EntropyArgs {            // k_entropy: per-tile symbol lists -> per-segme
     int32_t seg_begin, seg_end;     // segments this launch codes (whole image: 0, num_segs)
     SegArrays seg;
 };
-int launch_entropy(const EntropyArgs &a, void *stream);
+int launch_entropy(const EntropyArgs &a, void *stream, void *const *ev = nullptr);
 
 // Post-processing (jpegamd_finalize.hip): global bit / stuffing offsets, stitch, stuffing, container -- ONE launch.
 struct FinalizeArgs {
@@ -119,7 +121,7 @@ struct FinalizeArgs {
     int32_t prefix_len;
     int32_t write_eoi;
 };
-int launch_finalize(const FinalizeArgs &a, void *stream);
+int launch_finalize(const FinalizeArgs &a, void *stream, void *const *ev = nullptr);
 int finalize_chunks(int num_segs);
 
 // Segment exchange for one image sharded over GPUs by block rows (jpegamd_finalize.hip): dense copy of the used words of

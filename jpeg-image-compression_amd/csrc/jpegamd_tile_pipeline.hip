@@ -17,6 +17,7 @@
 //
 // Extra HBM traffic: 4 bytes per symbol written and read once (~25 MB per 8192^2 photo-like image, vs
 // 201 MB of pixels).  Lists are reserved at the worst case (65 items per block) so any content fits.
+#include <hip/hip_ext.h>
 #include "jpegamd_device.h"
 
 namespace jpegamd {
@@ -756,7 +757,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #endif
 }
 
-int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream) {
+int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream, void *const *ev) {
     // persistent: at most 2 workgroups per CU (16 waves/CU at 4 waves/SIMD), fewer for small images
     const int ntiles = im.tile_end - im.tile_begin;
     if (ntiles <= 0) return 0;
@@ -771,6 +772,7 @@ int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool ta
     sch.tpr_magic = magic > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)magic;   // tiles_per_row == 1: the correction step makes up for it
     const dim3 grid(wgs), block(64 * kWavesT);
     if (taps) hipLaunchKernelGGL(k_tile_transform<true>, grid, block, 0, (hipStream_t)stream, im, out, sch);
+    else if (ev) hipExtLaunchKernelGGL(k_tile_transform<false>, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, im, out, sch);
     else hipLaunchKernelGGL(k_tile_transform<false>, grid, block, 0, (hipStream_t)stream, im, out, sch);
     return (int)hipGetLastError();
 }

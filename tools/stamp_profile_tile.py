@@ -73,4 +73,5 @@ hist, edges = np.histogram(end, bins=np.arange(np.floor(end.min()), np.ceil(end.
 print("waves finishing per microsecond:", " ".join(f"{int(e)}:{c}" for e, c in zip(edges[:-1], hist)))
 busy = np.array([(end > t).sum() for t in np.arange(0.0, end.max(), 1.0)])
 print("waves still running at t (us):", " ".join(f"{int(t)}:{b}" for t, b in zip(np.arange(0.0, end.max(), 1.0), busy) if t >= end.min() - 2))
+os.makedirs(str(ROOT / "gpurun_out" / "stamps"), exist_ok=True)
 np.save(str(ROOT / "gpurun_out" / "stamps" / (os.path.basename(os.environ.get("JPEGAMD_LIB", "default")) + ".npy")), buf)
