@@ -9,7 +9,7 @@ import csv,collections
 rows=list(csv.DictReader(open("$R/gpurun_out/launch_cost/t_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 
-per=max(1,len(rows)//20)
+per=max(1,len(rows)//int("${2:-20}"))
 d=collections.defaultdict(list)
 for i,r in enumerate(rows): d[(i%per, r["Kernel_Name"])].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1000)
 for (i,k),v in sorted(d.items()):
