@@ -6,29 +6,35 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 Rank 0 prints ONE JSON line.
 
 Workloads (`--workload`, default `auto`):
-  image8192  BASELINE.json configs[2], the config the metric and the roofline target are quoted on: one 8192x8192
-             synthetic 24-bit BMP per rank per step, 3 rotating inputs per rank (603 MB > the 256 MiB Infinity Cache).
+  image8192  BASELINE.json configs[2], the config the metric and the roofline target are quoted on: 8192x8192 synthetic
+             24-bit BMPs.  By default a step codes FOUR of them (distinct pictures, 8 in rotation per rank: 1.6 GB > the
+             256 MiB Infinity Cache) through ONE launch of each kernel (`--images-per-launch`, jpegamd_encode_batch_async):
+             the launch, prologue and drain costs of the three kernels are paid once per four images.  `--images-per-launch
+             1` is the single-image step of round 1 (3 rotating inputs); its kernel durations are also measured in every
+             default run and reported as roofline.one_image_per_launch.
              This is what `auto` selects at EVERY N: the driver derives the scaling efficiency from the per-N values, so
              the per-rank work has to be the same at N = 1 and N = 8 (weak scaling).
   batch4096  BASELINE.json configs[3]: independent 4096x4096 images, 8 per rank per step (N = 8: the batch of 64),
-             distinct seeds (tests/golden/batch4096.json holds the compiled reference's answers for all 64), every
-             finished bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
+             distinct seeds (tests/golden/batch4096.json holds the compiled reference's answers for all 64), by default one
+             launch per step; every finished bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
 Reference quantisation table (Q=50) unless --quality says otherwise; pixel rows resident in HBM; output = complete
 JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_transform -> k_entropy -> k_finalize) over the
-step's images.  Steps alternate over `--streams` encoder contexts / HIP streams (default 4) so the latency-bound tail
-kernels of one image overlap the transform of the next; every step is still a complete encode.  With N > 1 every rank
+step's images.  Launches alternate over `--streams` encoder contexts / HIP streams (default 4) so the latency-bound tail
+kernels of one launch overlap the transform of the next; every step is still a complete encode.  With N > 1 every rank
 encodes its own images (weak scaling, no data-path collective inside the encode) and the finished bitstreams are
 collected at rank 0 with one asynchronous RCCL gather per `--gather-every` images
 (jpegamd.sharding.BatchedStreamGather), overlapped with the following steps.
 
 Extra objects on the JSON line:
-  "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes (BMP rows read + JFIF bytes
-                  written, per image) / SUM of the kernels' durations / 8 TB/s.  Durations are HIP-event timed inside
+  "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes of ONE launch (BMP rows read + JFIF
+                  bytes written, per image x images_per_launch) / SUM of the three kernels' durations / 8 TB/s.  Durations are HIP-event timed inside
                   this run through the C-ABI's event ring: every kernel is launched with its own begin / end events
                   on the stream it runs on (a kernel's own duration, as a kernel trace shows it); with several
                   streams they come from a single-stream pass right after the timed region (kernels of different images
-                  overlap in the timed region).  `dominant_frac` is the same bytes over k_tile_transform alone,
-                  `hbm_read_frac` the read bytes alone over the sum.
+                  overlap in the timed region): once right behind the region (`sustained`) and once 250 ms later (the
+                  headline figures; the state a kernel trace of `bench.py --streams 1` sees).  `dominant_frac` is the
+                  same bytes over k_tile_transform alone, `hbm_read_frac` the read bytes alone over the sum,
+                  `per_image_us` the sum divided by images_per_launch.
   "cpu_baseline"  the compiled reference natural_c (oracle/_ref), single thread, on a bounded sample: with its own
                   flags (no -O) and with -O2; rank 0, N == 1 only.
 """
@@ -63,6 +69,8 @@ def parse_args():
     ap.add_argument("--kind", type=int, default=0, help="synthetic content: 0 photo-like, 1 noise, 2 flat, 3 gradient")
     ap.add_argument("--quality", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--images-per-launch", type=int, default=0, choices=[0, 1, 2, 4, 8],
+                    help="images coded by ONE launch of each kernel (jpegamd_encode_batch_async); 0 = 4 for image8192 (that many images per step), 8 for batch4096")
     ap.add_argument("--roofline-idle-ms", type=float, default=250.0, help="idle time in front of the second single-stream roofline pass")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams (one encoder context each) the images alternate over; >1 lets the latency-bound tail "
@@ -197,9 +205,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     workload = args.workload if args.workload != "auto" else "image8192"
+    B = args.images_per_launch or (4 if workload == "image8192" else 8)
     if workload == "image8192":
-        w, h, ips = args.width or 8192, args.height or 8192, 1
-        seeds = [1000 + rank * ROTATE + i for i in range(ROTATE)]
+        w, h, ips = args.width or 8192, args.height or 8192, B
+        nrot = ROTATE if B == 1 else max(ROTATE, 2 * B)          # a launch reads B distinct pictures, two launches never the same ones
+        seeds = [1000 + rank * nrot + i for i in range(nrot)]
     else:
         w, h, ips = args.width or 4096, args.height or 4096, BATCH_PER_RANK
         seeds = [2000 + rank * BATCH_PER_RANK + i for i in range(BATCH_PER_RANK)]
@@ -207,9 +217,9 @@ def main():
     inputs, stride, first_bmp = make_inputs(args, rank, torch, jpegamd, w, h, seeds)
     nimg = len(inputs)
     nstreams = max(1, args.streams)
-    encs = [jpegamd.Encoder(w, h) for _ in range(nstreams)]
+    encs = [jpegamd.Encoder(w, B * ((h + 7) // 8 * 8)) for _ in range(nstreams)]
     cap = 4096 + w * h // 2 if args.kind != 1 and args.quality <= 75 else 4096 + 2 * w * h     # >10x the typical photo-like output
-    nbuf = max(2 * nstreams, nimg)
+    nbuf = max(2 * nstreams * B, nimg, B + 1)
     outs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(nbuf)]
     imgs = [jpegamd.Encoder.image(t.data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, args.quality) for t in inputs]
@@ -236,25 +246,30 @@ def main():
             rec_ptrs[st_i] = (pl.data_ptr(), pl.numel(), sz.data_ptr(), sz)
     last_image = [-1]
 
-    def encode_image(n):
-        """n-th image of the run (n = step * ips + j)."""
-        si = n % nstreams                                         # images alternate over the streams / contexts
+    def encode_launch(m):
+        """m-th launch of the run: images n = m * B .. m * B + B - 1 (image n of the run is picture n % nimg)."""
+        si = m % nstreams                                         # launches alternate over the streams / contexts
         with torch.cuda.stream(tstreams[si]):
+            ns = list(range(m * B, m * B + B))
             if gather is None:
-                b = n % nbuf
-                encs[si].encode_async(imgs[n % nimg], outs[b].data_ptr(), cap, sizes[b].data_ptr(), True, tstreams[si].cuda_stream)
+                optrs = [(outs[n % nbuf].data_ptr(), cap, sizes[n % nbuf].data_ptr()) for n in ns]
             else:
-                if n % G < nstreams:                              # a stream's first write into this buffer: behind the
-                    gather.reserve(n)                             # collective that last read it
-                optr, ocap, sptr, _ = rec_ptrs[n % (2 * G)]
-                encs[si].encode_async(imgs[n % nimg], optr, ocap, sptr, True, tstreams[si].cuda_stream)
-                if n % G == G - 1:
-                    commit(n, False)
-        last_image[0] = n
+                for n in ns:
+                    if n % G < nstreams * B:                      # a stream's first write into this buffer: behind the
+                        gather.reserve(n)                         # collective that last read it
+                optrs = [rec_ptrs[n % (2 * G)][:3] for n in ns]
+            if B == 1:
+                encs[si].encode_async(imgs[ns[0] % nimg], optrs[0][0], optrs[0][1], optrs[0][2], True, tstreams[si].cuda_stream)
+            else:
+                encs[si].encode_batch_async([imgs[n % nimg] for n in ns], [o[0] for o in optrs], min(o[1] for o in optrs),
+                                            [o[2] for o in optrs], True, tstreams[si].cuda_stream)
+            if gather is not None and ns[-1] % G == G - 1:
+                commit(ns[-1], False)
+        last_image[0] = m * B + B - 1
 
     def step(i):
-        for j in range(ips):
-            encode_image(i * ips + j)
+        for j in range(ips // B):
+            encode_launch(i * (ips // B) + j)
 
     def commit(n, force):
         cur = torch.cuda.current_stream()
@@ -288,7 +303,8 @@ def main():
         check_capacity("warm-up")
 
     n_timed = K * ips
-    per_ctx = (n_timed + nstreams - 1) // nstreams
+    n_launches = n_timed // B
+    per_ctx = (n_launches + nstreams - 1) // nstreams
     for e in encs:
         e.set_profiling(per_ctx)
     if dist is not None:
@@ -309,9 +325,10 @@ def main():
         elapsed = float(t.item())
 
     last = (W + K) * ips - 1
-    st = encs[last % nstreams].finish()                           # raises if ANY timed encode overflowed on that context
+    last_ctx = (last // B) % nstreams
+    st = encs[last_ctx].finish()                                  # raises if ANY timed encode overflowed on that context
     for si, e in enumerate(encs):
-        if si != last % nstreams and n_timed > si:
+        if si != last_ctx and n_launches > si:
             e.finish()
     if gather is not None:                                        # every record of the last buffers carries a plausible size
         for k in range(min(2 * G, n_timed)):
@@ -323,8 +340,8 @@ def main():
         prof = [e.profile(s) for e, n_calls in pairs for s in range(n_calls)]
         return tuple(sum(getattr(p, f) for p in prof) / max(1, len(prof)) for f in ("ns_transform", "ns_entropy", "ns_pack", "ns_total"))
 
-    first_timed = W * ips
-    ov_tr, ov_en, ov_pk, ov_tot = mean_profile([(e, len([n for n in range(first_timed, first_timed + n_timed) if n % nstreams == si]))
+    first_timed = W * ips // B
+    ov_tr, ov_en, ov_pk, ov_tot = mean_profile([(e, len([m for m in range(first_timed, first_timed + n_launches) if m % nstreams == si]))
                                                  for si, e in enumerate(encs)])
     # Kernel durations for the roofline.  The library launches every kernel with its own begin / end events
     # (hipExtLaunchKernelGGL), so a duration is the kernel's own, as in a kernel trace -- but with several streams the
@@ -334,43 +351,70 @@ def main():
     # HBM-bound k_tile_transform runs ~15-20 % longer there, the other two kernels a little shorter) and one after a short
     # idle.  `roofline` is built from the second, the state a kernel trace of `bench.py --streams 1` sees (its launch gaps
     # keep the GPU a quarter idle); the first is reported beside it as `sustained`.
-    sustained = None
-    if nstreams > 1:
-        P, SKIP = 70, 10                                      # the first SKIP images of a pass (clock ramp after the idle) are not averaged
+    sustained, single_ns = None, None
+    P, SKIP = 70, 10                                          # the first SKIP launches of a pass (clock ramp after the idle) are not averaged
 
-        def single_stream_pass():
-            encs[0].set_profiling(P)
-            torch.cuda.synchronize()
-            for i in range(P):
+    def single_stream_pass(nb):
+        """P launches of nb images each on stream 0 -> mean own durations of the three kernels (ns per launch)."""
+        encs[0].set_profiling(P)
+        torch.cuda.synchronize()
+        for i in range(P):
+            if nb == 1:
                 encs[0].encode_async(imgs[i % nimg], outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
-            torch.cuda.synchronize()
-            encs[0].finish()
-            prof = [encs[0].profile(s) for s in range(SKIP, P)]
-            return tuple(sum(getattr(p, f) for p in prof) / len(prof) for f in ("ns_transform", "ns_entropy", "ns_pack", "ns_total"))
+            else:
+                ns = [(i * nb + j) % nimg for j in range(nb)]
+                encs[0].encode_batch_async([imgs[n] for n in ns], [outs[j].data_ptr() for j in range(nb)], cap,
+                                           [sizes[j].data_ptr() for j in range(nb)], True, tstreams[0].cuda_stream)
+        torch.cuda.synchronize()
+        encs[0].finish()
+        prof = [encs[0].profile(s) for s in range(SKIP, P)]
+        return tuple(sum(getattr(p, f) for p in prof) / len(prof) for f in ("ns_transform", "ns_entropy", "ns_pack", "ns_total"))
 
-        h_tr, h_en, h_pk, _ = single_stream_pass()
+    if nstreams > 1:
+        h_tr, h_en, h_pk, _ = single_stream_pass(B)
         sustained = {"transform_us": round(h_tr / 1e3, 2), "entropy_us": round(h_en / 1e3, 2), "pack_us": round(h_pk / 1e3, 2),
-                     "sum_kernels_us": round((h_tr + h_en + h_pk) / 1e3, 2), "measured": f"single-stream pass of {P - SKIP} images right behind the timed region"}
+                     "sum_kernels_us": round((h_tr + h_en + h_pk) / 1e3, 2), "measured": f"single-stream pass of {P - SKIP} launches right behind the timed region"}
         time.sleep(args.roofline_idle_ms / 1e3)
-        ns_tr, ns_en, ns_pk, ns_tot = single_stream_pass()
-        roof_note = f"single-stream pass of {P - SKIP} images, {args.roofline_idle_ms:.0f} ms after the timed region"
+        ns_tr, ns_en, ns_pk, ns_tot = single_stream_pass(B)
+        roof_note = f"single-stream pass of {P - SKIP} launches, {args.roofline_idle_ms:.0f} ms after the timed region"
     else:
         ns_tr, ns_en, ns_pk, ns_tot = ov_tr, ov_en, ov_pk, ov_tot
         roof_note = "timed region (single stream)"
+    if B > 1:                                                  # the same three kernels over ONE image per launch, for comparison
+        single_ns = single_stream_pass(1)
     ns_sum = ns_tr + ns_en + ns_pk                                # sum of the kernels' own durations (no launch gaps)
 
-    # parity spot check of the last image against the committed natural_c golden
-    encs[0].encode_async(imgs[last % nimg], outs[1].data_ptr(), cap, sizes[1].data_ptr(), True, tstreams[0].cuda_stream)
-    encs[0].finish()
-    out_bytes = bytes(outs[1][: int(sizes[1].item())].cpu().numpy())
+    # parity spot check against the committed natural_c golden: the last image of the run (B = 1), or one more batched launch
+    # whose first picture has a golden (goldens exist for the first three seeds of rank 0) and whose other outputs must equal
+    # single-image encodes of the same pictures
+    batch_self_ok = True
+    if B == 1:
+        pick = last % nimg
+        encs[0].encode_async(imgs[pick], outs[1].data_ptr(), cap, sizes[1].data_ptr(), True, tstreams[0].cuda_stream)
+        encs[0].finish()
+        out_bytes = bytes(outs[1][: int(sizes[1].item())].cpu().numpy())
+    else:
+        pick = 0
+        encs[0].encode_batch_async([imgs[j % nimg] for j in range(B)], [outs[j].data_ptr() for j in range(B)], cap,
+                                   [sizes[j].data_ptr() for j in range(B)], True, tstreams[0].cuda_stream)
+        encs[0].finish()
+        batch_out = [bytes(outs[j][: int(sizes[j].item())].cpu().numpy()) for j in range(B)]
+        out_bytes = batch_out[0]
+        for j in range(1, B):
+            encs[0].encode_async(imgs[j % nimg], outs[B].data_ptr(), cap, sizes[B].data_ptr(), True, tstreams[0].cuda_stream)
+            encs[0].finish()
+            batch_self_ok = batch_self_ok and batch_out[j] == bytes(outs[B][: int(sizes[B].item())].cpu().numpy())
     parity, parity_ok = "unchecked", True
     gold_file = ROOT / "tests" / "golden" / ("large.json" if workload == "image8192" else "batch4096.json")
     if gold_file.exists() and rank == 0:
-        key = f"{w}x{h}_seed{seeds[last % nimg]}_kind{args.kind}_q{args.quality}"
+        key = f"{w}x{h}_seed{seeds[pick]}_kind{args.kind}_q{args.quality}"
         ent = json.loads(gold_file.read_text()).get(key)
         if ent:
             parity_ok = ent["sha256"] == hashlib.sha256(out_bytes).hexdigest() and ent["size"] == len(out_bytes)
             parity = "sha256 == natural_c golden" if parity_ok else "MISMATCH vs natural_c golden"
+            if B > 1:
+                parity += " (picture 0 of a batched launch; pictures 1.. equal their single-image encodes)" if batch_self_ok else "; MISMATCH batched vs single-image encode"
+                parity_ok = parity_ok and batch_self_ok
 
     if gather is not None and rank == 0:
         per_rank = gather.result(last)
@@ -394,6 +438,7 @@ def main():
     mpx = w * h / 1e6
     read_bytes = stride * h
     algo_bytes = read_bytes + len(out_bytes)
+    launch_bytes = algo_bytes * B                                 # algorithmic bytes of ONE launch of each kernel (B images; the last image's size stands for all)
     traffic = None
     tf = ROOT / "profiles" / "hbm_traffic.json"
     if tf.exists():
@@ -418,20 +463,27 @@ def main():
                                 f"{nimg} distinct inputs/rank" + (" (BASELINE configs[3]: batch of 64 at 8 ranks)" if workload == "batch4096" else
                                                                    " (BASELINE configs[2])")),
                    "images_per_step": world * ips,
+                   "images_per_launch": B,
                    "streams_per_rank": nstreams,
                    "parallelism": f"dp{world} (independent images per rank"
                                   + (", async RCCL gather of bitstreams to rank 0)" if dist is not None else ")")},
         "roofline": {"bound": "hbm", "kernel": "k_tile_transform + k_entropy + k_finalize (sum of durations, SURVEY.md 8d)",
-                     "achieved": round(algo_bytes / ns_sum, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(algo_bytes / ns_sum / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes": algo_bytes,
-                     "hbm_read_frac": round(read_bytes / ns_sum / HBM_PEAK_GBS, 4),
-                     "dominant_kernel": "k_tile_transform", "dominant_frac": round(algo_bytes / ns_tr / HBM_PEAK_GBS, 4),
+                     "achieved": round(launch_bytes / ns_sum, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(launch_bytes / ns_sum / HBM_PEAK_GBS, 4), "traffic": (traffic * B if traffic else None),
+                     "algorithmic_bytes": launch_bytes, "images_per_launch": B,
+                     "hbm_read_frac": round(read_bytes * B / ns_sum / HBM_PEAK_GBS, 4),
+                     "dominant_kernel": "k_tile_transform", "dominant_frac": round(launch_bytes / ns_tr / HBM_PEAK_GBS, 4),
+                     "per_image_us": round(ns_sum / B / 1e3, 2),
                      "kernel_us": round(ns_tr / 1e3, 2), "entropy_us": round(ns_en / 1e3, 2), "pack_us": round(ns_pk / 1e3, 2),
                      "sum_kernels_us": round(ns_sum / 1e3, 2), "first_to_last_event_us": round(ns_tot / 1e3, 2),
                      "throughput_frac": round(algo_bytes * ips / (elapsed / K * 1e9) / HBM_PEAK_GBS, 4),
                      "measured": roof_note,
-                     "sustained": (dict(sustained, frac=round(algo_bytes / (sustained["sum_kernels_us"] * 1e3) / HBM_PEAK_GBS, 4)) if sustained else None),
+                     "one_image_per_launch": ({"transform_us": round(single_ns[0] / 1e3, 2), "entropy_us": round(single_ns[1] / 1e3, 2),
+                                               "pack_us": round(single_ns[2] / 1e3, 2), "sum_kernels_us": round(sum(single_ns[:3]) / 1e3, 2),
+                                               "frac": round(algo_bytes / sum(single_ns[:3]) / HBM_PEAK_GBS, 4),
+                                               "measured": f"single-stream pass of {P - SKIP} single-image launches behind the batched one"}
+                                              if single_ns else None),
+                     "sustained": (dict(sustained, frac=round(launch_bytes / (sustained["sum_kernels_us"] * 1e3) / HBM_PEAK_GBS, 4)) if sustained else None),
                      "overlapped_us": {"transform": round(ov_tr / 1e3, 2), "entropy": round(ov_en / 1e3, 2),
                                        "pack": round(ov_pk / 1e3, 2), "total": round(ov_tot / 1e3, 2)}},
         "host_issue_us_per_step": round((t_issued - t0) / K * 1e6, 2),

@@ -118,6 +118,19 @@ int32_t jpegamd_encode_async(JpegAmdEncoder *enc, const JpegAmdImage *img, void 
                              uint64_t out_capacity, uint64_t *out_size_dev,
                              int32_t with_container, void *stream);
 
+/* Enqueue the encode of `count` images (1 .. JPEGAMD_MAX_BATCH) of ONE geometry -- same width, height, row_stride,
+ * bottom_up, channel_order and quality, different pixels -- as ONE launch of each kernel: the reference codes one file per
+ * process (natural_c/src/main.c:21-24), a server codes many, and small images leave a launch per image mostly idle (a 4096^2
+ * image gives every wave of the transform two tiles).  outs_dev[i] / out_sizes_dev[i] receive image i's bytes and byte
+ * count; every output has out_capacity bytes.  The context must have been created for at least count x the tiles and
+ * segments of one image (e.g. jpegamd_encoder_create(W, count * H) for count W x H images -- max_height may go up to
+ * JPEGAMD_MAX_BATCH x 65535 for that purpose); JPEGAMD_ERR_TOO_LARGE otherwise.
+ * jpegamd_encoder_finish then reports the LAST image's size and the batch's summed counters. */
+#define JPEGAMD_MAX_BATCH 8
+int32_t jpegamd_encode_batch_async(JpegAmdEncoder *enc, const JpegAmdImage *imgs, int32_t count, void *const *outs_dev,
+                                   uint64_t out_capacity, uint64_t *const *out_sizes_dev, int32_t with_container,
+                                   void *stream);
+
 /* Block until the last enqueued encode on this context finished; optionally fetch stats
  * (stats may be NULL).  Returns JPEGAMD_ERR_HUFF_CAPACITY if the output did not fit. */
 int32_t jpegamd_encoder_finish(JpegAmdEncoder *enc, JpegAmdStats *stats);

@@ -132,7 +132,8 @@ extern "C" uint64_t jpegamd_max_jfif_bytes(int32_t width, int32_t height) {
     } while (0)
 
 extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_width, int32_t max_height) {
-    if (!out || max_width <= 0 || max_height <= 0 || max_width > 65535 || max_height > 65535) return JPEGAMD_ERR_ARG;
+    // (an image is at most 65535 rows -- describe() checks that; a context may reserve room for a batch of them)
+    if (!out || max_width <= 0 || max_height <= 0 || max_width > 65535 || max_height > 65535 * kMaxBatch) return JPEGAMD_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -260,6 +261,10 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     d->num_tiles = d->tiles_per_row * d->blocks_h;
     d->tile_begin = 0; d->tile_end = d->num_tiles;
     d->seg_begin = 0; d->seg_end = d->num_segs;
+    d->batch = 1;
+    for (int i = 0; i < kMaxBatch; ++i) d->batch_pixels[i] = d->pixels;
+    const uint64_t tpi = 0x100000000ull / (uint64_t)d->num_tiles;
+    d->tpi_magic = tpi > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tpi;
     d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0) ? 1 : 0;
     if (e && !context_fits(e, img->width, img->height)) return JPEGAMD_ERR_TOO_LARGE;
     return JPEGAMD_OK;
@@ -284,8 +289,23 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     ea.tile_items = e->tile_items;
     ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
     ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
+    ea.tiles_per_image = im.batch > 1 ? im.num_tiles : 0;
     ea.seg = e->seg;
     return launch_entropy(ea, stream, ev ? (void *const *)(ev + 2) : nullptr);
+}
+
+static int run_finalize_batch(JpegAmdEncoder *e, const ImageDesc &im, void *const *outs_dev, uint64_t out_capacity,
+                              uint64_t *const *out_sizes_dev, int32_t with_container, hipStream_t stream, hipEvent_t *ev = nullptr) {
+    FinalizeArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.seg = e->seg;
+    fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
+    fa.batch = im.batch;
+    for (int i = 0; i < im.batch; ++i) { fa.out[i] = (uint8_t *)outs_dev[i]; fa.out_size[i] = out_sizes_dev[i]; }
+    fa.out_capacity = out_capacity; fa.stats = e->stats_dev;
+    fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
+    fa.write_eoi = with_container ? 1 : 0;
+    return launch_finalize(fa, stream, (void *const *)ev);
 }
 
 static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, uint64_t out_capacity, uint64_t *out_size_dev,
@@ -294,7 +314,8 @@ static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, u
     std::memset(&fa, 0, sizeof(fa));
     fa.seg = e->seg;
     fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
-    fa.out = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size = out_size_dev; fa.stats = e->stats_dev;
+    fa.batch = 1;
+    fa.out[0] = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size[0] = out_size_dev; fa.stats = e->stats_dev;
     fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
     fa.write_eoi = with_container ? 1 : 0;
     return launch_finalize(fa, stream, (void *const *)ev);
@@ -412,6 +433,48 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
     if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
     if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
+    e->last_stream = stream;
+    e->pending = true;
+    e->timed = timed;
+    return JPEGAMD_OK;
+}
+
+// `count` images of one geometry through ONE launch of each kernel (see the header): image i's tiles are
+// [i * num_tiles, (i + 1) * num_tiles), its segments [i * num_segs, ..); DC prediction, bit offsets and stuffing restart per image.
+extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdImage *imgs, int32_t count, void *const *outs_dev,
+                                              uint64_t out_capacity, uint64_t *const *out_sizes_dev, int32_t with_container,
+                                              void *stream_) {
+    if (!e || !imgs || !outs_dev || !out_sizes_dev || count < 1 || count > kMaxBatch) return JPEGAMD_ERR_ARG;
+    ImageDesc im;
+    int32_t rc = describe(e, &imgs[0], &im);
+    if (rc) return rc;
+    for (int i = 0; i < count; ++i) {
+        const JpegAmdImage &g = imgs[i];
+        if (!outs_dev[i] || !out_sizes_dev[i] || !g.pixels) return JPEGAMD_ERR_ARG;
+        if (g.width != imgs[0].width || g.height != imgs[0].height || g.row_stride != imgs[0].row_stride ||
+            (g.bottom_up != 0) != (imgs[0].bottom_up != 0) || g.channel_order != imgs[0].channel_order || g.quality != imgs[0].quality)
+            return JPEGAMD_ERR_ARG;
+        im.batch_pixels[i] = (const uint8_t *)g.pixels;
+        if ((((uintptr_t)g.pixels) & 3u) != 0) im.fast_ok = 0;
+    }
+    if ((int64_t)count * im.num_tiles > e->max_tiles || (int64_t)count * im.num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
+    im.batch = count;
+    im.tile_end = count * im.num_tiles;
+    im.seg_end = count * im.num_segs;
+    rc = prepare_constants(e, &imgs[0], with_container != 0);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+
+    const bool timed = !e->ring.empty();
+    hipEvent_t *ev = nullptr;
+    if (timed) {
+        e->last_slot = (int)(e->calls % e->ring.size());
+        ev = e->ring[(size_t)e->last_slot].ev;
+        ++e->calls;
+    }
+    if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+    if (run_finalize_batch(e, im, outs_dev, out_capacity, out_sizes_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    e->last_segs = count * im.num_segs;
     e->last_stream = stream;
     e->pending = true;
     e->timed = timed;

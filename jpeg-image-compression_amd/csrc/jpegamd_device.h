@@ -44,16 +44,16 @@ __device__ __forceinline__ int ref_quantise(float coef, float qstep) {
 // ------------------------------------------------------------------------------------
 // Pixel access
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ const uint8_t *row_ptr(const ImageDesc &im, int y) {
+__device__ __forceinline__ const uint8_t *row_ptr(const ImageDesc &im, const uint8_t *pixels, int y) {
     const int stored = im.bottom_up ? (im.height - 1 - y) : y;      // bmp_handler.c:109
-    return im.pixels + (size_t)stored * (size_t)im.row_stride;
+    return pixels + (size_t)stored * (size_t)im.row_stride;
 }
 
 // Luma of image pixel (x, y) with the converter's edge clamp (converter.c:31,36,51).
-__device__ __forceinline__ int luma_clamped(const ImageDesc &im, int x, int y) {
+__device__ __forceinline__ int luma_clamped(const ImageDesc &im, const uint8_t *pixels, int x, int y) {
     x = min(x, im.width - 1);
     y = min(y, im.height - 1);
-    const uint8_t *p = row_ptr(im, y) + 3 * (size_t)x;
+    const uint8_t *p = row_ptr(im, pixels, y) + 3 * (size_t)x;
     const uint32_t w = im.weights;
     return (int)(((w & 0xFF) * p[0] + ((w >> 8) & 0xFF) * p[1] + ((w >> 16) & 0xFF) * p[2]) >> 8);
 }

@@ -109,10 +109,13 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     if (seg >= a.seg_end) return;                   // wave-uniform: every wave below runs with all 64 lanes
     uint32_t *win = s_win[wave];
 
-    const int by = seg / a.segs_per_row;
-    const int tx0 = (seg - by * a.segs_per_row) * kSegTiles;
+    const int image = a.tiles_per_image ? seg / a.num_segs : 0;     // a batch: every image has num_segs segments and tiles_per_image tiles
+    const int sl = seg - image * a.num_segs;
+    const int by = sl / a.segs_per_row;
+    const int tx0 = (sl - by * a.segs_per_row) * kSegTiles;
     const int ntiles = min(kSegTiles, a.tiles_per_row - tx0);
-    const int tile0 = by * a.tiles_per_row + tx0;
+    const int tile_in_image = by * a.tiles_per_row + tx0;
+    const int tile0 = image * a.tiles_per_image + tile_in_image;
 
 #pragma unroll
     for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     // The segment's tiles: lane t < ntiles holds tile t's numbers.
     const uint32_t *trec = a.tile_items + (size_t)(tile0 + lane) * kTileItemCap + kTileRecord;      // {items, last DC, exact count, 0}
     const uint4 rec = lane < ntiles ? *reinterpret_cast<const uint4 *>(trec) : make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t tprev = (lane < ntiles && tile0 + lane > 0) ? trec[1 - kTileItemCap] : 0u;     // the tile before: its last DC (rle.c:59-70)
+    const uint32_t tprev = (lane < ntiles && tile_in_image + lane > 0) ? trec[1 - kTileItemCap] : 0u;   // the tile before (of the same image): its last DC (rle.c:59-70)
     const uint32_t pcnt = (rec.x + 1u) & ~1u;                                                      // list length incl. the padding item
     const uint32_t pincl = wave_incl_scan_u32(pcnt);
     const uint32_t pstart = pincl - pcnt;                                                           // stream index of the tile's first item

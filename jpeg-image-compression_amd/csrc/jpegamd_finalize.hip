@@ -30,7 +30,8 @@ __device__ __forceinline__ uint32_t fin_bits_at(const uint32_t *__restrict__ w, 
 
 // The `need` (1..7) bits that precede segment `s` in the stream (s may equal num_segs): only for predecessors shorter
 // than a byte, and for the final flush.
-__device__ __forceinline__ uint32_t fin_tail_bits(const FinalizeArgs &a, int s, int need) {
+template <class View>
+__device__ __forceinline__ uint32_t fin_tail_bits(const View &a, int s, int need) {
     uint32_t val = 0;
     int got = 0;
     for (int sp = s - 1; got < need && sp >= 0; --sp) {
@@ -68,10 +69,37 @@ __device__ __forceinline__ uint32_t fin_ff_mask(uint32_t w) {
     return t & 0x01010101u;
 }
 
-__global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs a) {
+// One image of the launch as the kernel body sees it: its own segment arrays (indices from 0), output and size word.
+struct FinalizeView {
+    SegArrays seg;
+    int32_t num_segs;
+    uint8_t *out;
+    uint64_t out_capacity;
+    uint64_t *out_size;
+    ScanStats *stats;
+    const uint8_t *prefix;
+    int32_t prefix_len, write_eoi;
+    bool last_image;                // its totals go to the per-call record
+};
+
+__global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs args) {
     __shared__ uint32_t s_wbits[kFinWaves], s_wff[kFinWaves];
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tid = (int)threadIdx.x;
-    const int g = (int)blockIdx.x;
+    // A batch: workgroup -> (image, chunk inside the image); everything below works on that image alone (bit offsets, byte
+    // phases and stuffing counts restart with every image).
+    const int image = args.batch > 1 ? (int)blockIdx.x / args.num_chunks : 0;
+    const int g = (int)blockIdx.x - image * args.num_chunks;
+    FinalizeView a;
+    {
+        const size_t s0 = (size_t)image * (size_t)args.num_segs;
+        a.seg.words = args.seg.words + s0 * kSegCapWords;
+        a.seg.bits = args.seg.bits + s0; a.seg.syms = args.seg.syms + s0; a.seg.exact = args.seg.exact + s0;
+        a.seg.edge = args.seg.edge + s0; a.seg.ffin = args.seg.ffin + s0 * 8;
+        a.num_segs = args.num_segs;
+        a.out = args.out[image]; a.out_capacity = args.out_capacity; a.out_size = args.out_size[image];
+        a.stats = args.stats; a.prefix = args.prefix; a.prefix_len = args.prefix_len; a.write_eoi = args.write_eoi;
+        a.last_image = image == args.batch - 1;
+    }
     const int s = g * kFinWaves + wave;
     const bool have = s < a.num_segs;
 
@@ -229,16 +257,19 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
         }
         if (!ok) atomicOr(&a.stats->status, 1u);
         *a.out_size = end;
-        a.stats->out_size = end;
-        a.stats->total_bits = b1;
-        a.stats->total_ff = chunk_ff0 + ff_in + running;
+        if (a.last_image) {
+            a.stats->out_size = end;
+            a.stats->total_bits = b1;
+            a.stats->total_ff = chunk_ff0 + ff_in + running;
+        }
     }
 }
 
 int launch_finalize(const FinalizeArgs &a, void *stream, void *const *ev) {
-    if (a.num_chunks <= 0) return 0;
-    if (ev) hipExtLaunchKernelGGL(k_finalize, dim3(a.num_chunks), dim3(64 * kFinWaves), 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
-    else hipLaunchKernelGGL(k_finalize, dim3(a.num_chunks), dim3(64 * kFinWaves), 0, (hipStream_t)stream, a);
+    if (a.num_chunks <= 0 || a.batch <= 0) return 0;
+    const dim3 grid((unsigned)(a.num_chunks * a.batch));
+    if (ev) hipExtLaunchKernelGGL(k_finalize, grid, dim3(64 * kFinWaves), 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
+    else hipLaunchKernelGGL(k_finalize, grid, dim3(64 * kFinWaves), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 

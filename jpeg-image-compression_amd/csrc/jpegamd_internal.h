@@ -64,14 +64,19 @@ struct ScanStats {                   // device-side per-call record
     uint32_t pad;
 };
 
+constexpr int kMaxBatch = 8;            // images of one geometry coded by ONE launch of each kernel (jpegamd_encode_batch_async)
+
 struct ImageDesc {
-    const uint8_t *pixels;
+    const uint8_t *pixels;              // image 0 (== batch_pixels[0])
+    const uint8_t *batch_pixels[kMaxBatch];
+    int32_t batch;                      // images in this launch; tiles / segments of image i are [i * num_tiles, ..) / [i * num_segs, ..)
+    uint32_t tpi_magic;                 // min(floor(2^32 / num_tiles), 2^32 - 1): global tile / num_tiles by multiply-high, at most one too small
     int32_t width, height, row_stride, bottom_up;
     uint32_t weights;          // luma weights for stored bytes 0,1,2 (byte 3 = 0)
     int32_t blocks_w, blocks_h, segs_per_row, num_segs;
     int32_t tiles_per_row, num_tiles;
-    int32_t tile_begin, tile_end;       // tiles this launch transforms (whole image: 0, num_tiles; a block-row shard otherwise)
-    int32_t seg_begin, seg_end;         // segments this launch codes
+    int32_t tile_begin, tile_end;       // tiles this launch transforms (whole images: 0, batch * num_tiles; a block-row shard otherwise)
+    int32_t seg_begin, seg_end;         // segments this launch codes (whole images: 0, batch * num_segs)
     int32_t fast_ok;           // pixels % 4 == 0 && row_stride % 4 == 0
 };
 
@@ -102,8 +107,9 @@ int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool ta
 struct EntropyArgs {            // k_entropy: per-tile symbol lists -> per-segment bit strings
     const uint32_t *tile_items;
     const uint32_t *huff;           // [272] (len << 16) | code: AC by run/size symbol, then 16 DC sizes
-    int32_t num_segs, segs_per_row, tiles_per_row;
-    int32_t seg_begin, seg_end;     // segments this launch codes (whole image: 0, num_segs)
+    int32_t num_segs, segs_per_row, tiles_per_row;     // per image
+    int32_t seg_begin, seg_end;     // segments this launch codes (whole images: 0, batch * num_segs)
+    int32_t tiles_per_image;        // a batch: segment s belongs to image s / num_segs, whose tiles start at image * tiles_per_image
     SegArrays seg;
 };
 int launch_entropy(const EntropyArgs &a, void *stream, void *const *ev = nullptr);
@@ -111,11 +117,12 @@ int launch_entropy(const EntropyArgs &a, void *stream, void *const *ev = nullptr
 // Post-processing (jpegamd_finalize.hip): global bit / stuffing offsets, stitch, stuffing, container -- ONE launch.
 struct FinalizeArgs {
     SegArrays seg;
-    int32_t num_segs;
-    int32_t num_chunks;             // workgroups = ceil(num_segs / 16)
-    uint8_t *out;
-    uint64_t out_capacity;
-    uint64_t *out_size;             // device
+    int32_t num_segs;               // per image
+    int32_t num_chunks;             // per image: workgroups = batch * ceil(num_segs / 16)
+    int32_t batch;
+    uint8_t *out[kMaxBatch];
+    uint64_t out_capacity;          // of every output
+    uint64_t *out_size[kMaxBatch];  // device
     ScanStats *stats;               // device
     const uint8_t *prefix;
     int32_t prefix_len;

@@ -303,9 +303,16 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     if (bid == 0 && threadIdx.x < kTileGroups) out.tile_ctr_next[threadIdx.x * 32] = 0u;   // all of them: the next launch may form more groups
     const int first = (bid >> sch.grp_shift) * kWavesT + wave;
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
-    struct TileGeo { int by, tbx0, nblk, bx; bool interior; };
+    struct TileGeo { int img, by, tbx0, nblk, bx; bool interior; };
     const auto geo = [&](int tile) {
         TileGeo g;
+        g.img = 0;
+        if (im.batch > 1) {                                     // a batch: image = tile / num_tiles, then the tile inside it
+            int i = (int)__umulhi((uint32_t)tile, im.tpi_magic), tl = tile - i * im.num_tiles;
+            if (tl >= im.num_tiles) { ++i; tl -= im.num_tiles; }
+            g.img = i;
+            tile = tl;
+        }
         int q = (int)__umulhi((uint32_t)tile, sch.tpr_magic), r = tile - q * im.tiles_per_row;   // tile / tiles_per_row
         if (r >= im.tiles_per_row) { ++q; r -= im.tiles_per_row; }
         g.by = q;
@@ -322,7 +329,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     const int32_t row_step = im.bottom_up ? -2 * im.row_stride : 2 * im.row_stride;
     const auto request_rows = [&](const TileGeo &g, RawRow (&raw)[4]) {
         const int row_low = im.bottom_up ? im.height - 8 - g.by * 8 : g.by * 8;
-        const uint8_t *tb = im.pixels + (size_t)row_low * (size_t)im.row_stride + 24 * (size_t)g.tbx0;
+        const uint8_t *tb = im.batch_pixels[g.img] + (size_t)row_low * (size_t)im.row_stride + 24 * (size_t)g.tbx0;
         uint32_t off = __umul24((uint32_t)(g.bx - g.tbx0), 24u) + row_term;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -361,7 +368,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    bfrag[s][j] = (_Float16)(float)(luma_clamped(im, px0 + j, py0 + 2 * s + h) - 128);
+                    bfrag[s][j] = (_Float16)(float)(luma_clamped(im, im.batch_pixels[tg.img], px0 + j, py0 + 2 * s + h) - 128);
         }
         TSTAMP(1);   // wait for the prefetched rows + luma
 #pragma unroll

@@ -15,7 +15,6 @@
 #include "jpegamd_device.h"
 
 namespace jpegamd {
-int launch_finalize(const FinalizeArgs &a, void *stream);
 int finalize_chunks(int num_segs);
 }
 using namespace jpegamd;

@@ -67,6 +67,7 @@ def _load() -> C.CDLL:
         "jpegamd_encoder_destroy": (i32, [vp]),
         "jpegamd_max_jfif_bytes": (u64, [i32, i32]),
         "jpegamd_encode_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
+        "jpegamd_encode_batch_async": (i32, [vp, C.POINTER(Image), i32, C.POINTER(C.c_void_p), u64, C.POINTER(C.c_void_p), i32, vp]),
         "jpegamd_encoder_finish": (i32, [vp, C.POINTER(Stats)]),
         "jpegamd_encoder_set_profiling": (i32, [vp, i32]),
         "jpegamd_encoder_profile": (i32, [vp, i32, C.POINTER(Stats)]),
@@ -101,7 +102,7 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
-EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async "
+EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async jpegamd_encode_batch_async "
             "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
             "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_table jpegamd_segment_meta_words jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
@@ -117,6 +118,7 @@ def quant_table(quality: int = 50):
     return table
 
 
+MAX_BATCH = 8                                                # JPEGAMD_MAX_BATCH
 SEG_META_WORDS = int(lib.jpegamd_segment_meta_words())      # metadata words per segment in the sharded-image exchange
 
 
@@ -258,6 +260,17 @@ class Encoder:
                                       1 if with_container else 0, C.c_void_p(stream))
         if rc:
             raise JpegAmdError(rc, "jpegamd_encode_async")
+
+    def encode_batch_async(self, imgs, out_ptrs, out_cap: int, size_ptrs, with_container: bool = True, stream: int = 0):
+        """`len(imgs)` images of one geometry (<= MAX_BATCH) through ONE launch of each kernel; the context must hold
+        len(imgs) x the tiles and segments of one image (e.g. Encoder(W, len(imgs) * H))."""
+        n = len(imgs)
+        arr = (Image * n)(*imgs)
+        outs = (C.c_void_p * n)(*[C.c_void_p(p) for p in out_ptrs])
+        sizes = (C.c_void_p * n)(*[C.c_void_p(p) for p in size_ptrs])
+        rc = lib.jpegamd_encode_batch_async(self._h, arr, n, outs, out_cap, sizes, 1 if with_container else 0, C.c_void_p(stream))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encode_batch_async")
 
     # ---- one image sharded over GPUs by block rows (include/jpeg_compression.h) ----
     def encode_rows_async(self, img: Image, row_begin: int, row_end: int, stream: int = 0):

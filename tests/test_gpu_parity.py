@@ -230,6 +230,46 @@ def test_reference_sample_images(jpegamd, dev):
     assert answers["lena.bmp"]["jpg_sha256"].startswith("95cf58fe")
 
 
+@pytest.mark.gpu
+def test_batched_launch_matches_the_oracle_image_by_image(jpegamd, oracle, dev):
+    """jpegamd_encode_batch_async: several images of one geometry through ONE launch of each kernel.  DC prediction
+    (rle.c:59-70), bit offsets and 0xFF stuffing (huffman.c:26-62) must restart with every image: each output equals the
+    oracle's file for that image alone.  Shapes: ragged widths (edge tiles, a short last segment), one tile per image,
+    several segments per row, noise (stuffing, dense lists on the direct path), Q != 50, segment only."""
+    rng = np.random.default_rng(77)
+    cases = [(8, 8, 3, 0, 0), (203, 117, 4, 1, 0), (512, 256, 8, 0, 1), (333, 250, 5, 2, 3), (2056, 72, 6, 0, 0), (1024, 1024, 8, 0, 0),
+             (640, 480, 2, 3, 2)]
+    for (w, h, n, kind, flags) in cases:
+        for quality, container in ((0, True), (90, True), (10, False)) if w in (203, 512) else ((0, True),):
+            enc = jpegamd.Encoder(w, n * ((h + 7) // 8) * 8 + 8)
+            bmps = [jpegamd.synth_bmp(w, h, 900 + 17 * i + w, kind, flags) for i in range(n)]
+            ups = [upload_pixels(b, jpegamd, dev) for b in bmps]
+            cap = 4096 + 2 * w * h
+            outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n)]
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n)]
+            imgs = [jpegamd.Encoder.image(px.data_ptr(), im.width, im.height, im.row_stride, bool(im.bottom_up), jpegamd.ORDER_BGR, quality)
+                    for im, px in ups]
+            enc.encode_batch_async(imgs, [o.data_ptr() for o in outs], cap, [s.data_ptr() for s in sizes], container,
+                                   torch.cuda.current_stream().cuda_stream)
+            st = enc.finish()
+            for i in range(n):
+                got = bytes(outs[i][:int(sizes[i].item())].cpu().numpy())
+                want = oracle.encode_bmp(bmps[i], quality=quality) if quality else oracle.encode_bmp(bmps[i])
+                if not container:
+                    want = want[328:-2]
+                assert got == want, (w, h, n, kind, flags, quality, container, i)
+            assert st.jfif_bytes == int(sizes[-1].item())
+    # a context that is too small for the batch refuses it
+    enc = jpegamd.Encoder(512, 512)
+    bmp = jpegamd.synth_bmp(512, 512, 1, 0, 0)
+    im, px = upload_pixels(bmp, jpegamd, dev)
+    d = jpegamd.Encoder.image(px.data_ptr(), 512, 512, im.row_stride, True)
+    out = torch.empty(1 << 20, dtype=torch.uint8, device=dev); size = torch.zeros(1, dtype=torch.int64, device=dev)
+    with pytest.raises(jpegamd.JpegAmdError):
+        enc.encode_batch_async([d, d], [out.data_ptr()] * 2, 1 << 20, [size.data_ptr()] * 2)
+
+
+
 def test_batch_of_64_4096_through_the_gather_path(jpegamd, dev):
     """BASELINE configs[3] at its stated shape on one GPU: 64 distinct 4096x4096 images encoded straight into the
     records of jpegamd.sharding.BatchedStreamGather (a one-rank RCCL group: the collective degenerates to a copy, the
