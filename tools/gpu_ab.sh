@@ -9,7 +9,7 @@ tail -1 $O/quick.log
 for round in 1 2; do
 for v in default "$@"; do
   L=$PWD/jpeg-image-compression_amd/libjpegamd.so; [ $v != default ] && L=$PWD/build_variants/lib_$v.so
-  JPEGAMD_LIB=$L timeout -k 10 200 python bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_$v.json 2> $O/bench_$v.err || [ $? -eq 3 ] || { tail -20 $O/bench_$v.err; exit 1; }
+  JPEGAMD_LIB=$L timeout -k 10 200 python bench.py --streams 1 --images-per-launch 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_$v.json 2> $O/bench_$v.err || [ $? -eq 3 ] || { tail -20 $O/bench_$v.err; exit 1; }
   python - <<PY
 import json
 d=json.load(open("$O/bench_$v.json")); r=d["roofline"]

@@ -7,7 +7,7 @@ timeout -k 10 300 python tests/manual/gpu_quick.py > $O/quick.log 2>&1 || { tail
 tail -1 $O/quick.log
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
 tail -2 $O/pytest_gpu.log
-timeout -k 10 200 python bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_s1.json 2> $O/bench_s1.err || { tail -20 $O/bench_s1.err; exit 1; }
+timeout -k 10 200 python bench.py --streams 1 --images-per-launch 1 --steps 200 --warmup 20 --no-cpu-baseline > $O/bench_s1.json 2> $O/bench_s1.err || { tail -20 $O/bench_s1.err; exit 1; }
 python - <<PY
 import json
 d=json.load(open("$O/bench_s1.json")); r=d["roofline"]

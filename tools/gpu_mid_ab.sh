@@ -7,4 +7,4 @@ timeout -k 10 300 python tests/manual/gpu_quick.py > $O/quick.log 2>&1 || { tail
 tail -1 $O/quick.log
 timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "${K:-goldens or random or large or sharded or segment or concurrent or quality}" > $O/pytest_gpu.log 2>&1 || { tail -40 $O/pytest_gpu.log; exit 1; }
 tail -2 $O/pytest_gpu.log
-for round in 1 2; do bash tools/gpu_trace.sh "$@" 2>&1 | grep -E "^==|k_tile|k_entropy|k_finalize|sum of"; done
+for round in 1 2; do BENCH_EXTRA="--images-per-launch 1" bash tools/gpu_trace.sh "$@" 2>&1 | grep -E "^==|k_tile|k_entropy|k_finalize|sum of"; done
