@@ -17,7 +17,7 @@ for tag, flags in (("", ""), ("_launch1", " --images-per-launch 1")):
         shutil.copy(r02 / f"kernel_stats{tag}.csv", dst / f"r02_kernel_stats{tag}.csv")
     if (r02 / f"trace{tag}.txt").exists():
         (dst / f"r02_kernel_trace_summary{tag}.txt").write_text(
-            f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1 --steps 100 --warmup 10 --no-cpu-baseline{flags}  (tools/gpu_trace.sh, tools/trace_gaps.py)\n"
+            f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1 --steps 100 --warmup 10 --no-cpu-baseline --no-one-image-pass{flags}  (tools/gpu_trace.sh, tools/trace_gaps.py)\n"
             + ("# default: 4 images of 8192^2 per launch -- divide a duration by 4 for the per-image figure\n" if not tag else "")
             + "".join(l for l in (r02 / f"trace{tag}.txt").read_text().splitlines(True) if "rocclr" not in l and "elementwise" not in l))
 
