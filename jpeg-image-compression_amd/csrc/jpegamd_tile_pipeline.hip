@@ -1,22 +1,22 @@
-// jpegamd_tile_pipeline.hip -- the transform and the entropy coder as TWO kernels.
+// jpegamd_tile_pipeline.hip -- k_tile_transform: pixels -> per-tile symbol lists (first of the pipeline's three kernels).
 //
-// Measurement that drove the split (profiles/, tools/stamp_profile.py): the fused kernel is bound by the
-// dependent latency of ONE wave walking through luma -> MFMA -> quantise -> compaction -> symbol batches
-// (a lone wave needs ~30 us for its 128 blocks), and its 128 live registers allow only 4 waves per SIMD
-// to overlap that latency.  Here
+// Persistent 512-thread workgroups; one wave-iteration per TILE of 32 blocks of one block row:
+//   luma (converter.c:31-51,60-90)            v_dot4 per pixel, straight into binary16 MFMA operands
+//   8x8 DCT (dct.c:63-96)                     the 64x64 LUT-product matrix on the matrix pipe, as two integer-valued binary16
+//                                             terms in separate accumulator chains: exact in any summation order
+//   quantisation (quantization.c:34-36)       guard-band quantiser; a coefficient within delta of a rounding tie is recomputed in
+//                                             the reference's own float order (one coefficient per wave pass)
+//   zigzag (zigzag.c:21-68)                   the matrix rows are stored in grouped zigzag order: no data movement
+//   RLE front half (rle.c:51-127)             DC DPCM inside the tile, non-zero compaction: every lane appends its block's
+//                                             symbols-to-be -- (zigzag position, value) items: DC, non-zero ACs, EOB -- to the
+//                                             tile's list, built in LDS and written out as four 16-byte-per-lane stores
+// k_entropy (jpegamd_entropy.hip) turns the lists of a segment's 8 tiles into one Huffman bit string, k_finalize
+// (jpegamd_finalize.hip) stitches the segments.  Tiles are handed out dynamically through 64 ticket counters; the next tile's
+// pixel rows are requested as soon as its ticket is in.  A launch covers one image, a block-row shard of one, or a batch of
+// images of one geometry (ImageDesc::batch).  DESIGN.md 4.0-4.1 has the measurements behind each choice.
 //
-//   k_tile_transform  one wave = one tile of 32 blocks: luma, the 64x64 DCT on the matrix pipe, guard-band
-//                     quantisation, exact-order fallback (identical to jpegamd_transform_mfma.hip), then
-//                     every lane APPENDS its block's symbols-to-be -- (zigzag position, value) items: DC,
-//                     non-zero ACs, EOB -- to the tile's list in HBM (plain stores at addresses from a
-//                     DPP prefix sum of per-lane counts).  No LDS list, no bit window, no segment state.
-//   k_entropy         one wave = one segment (4 tiles = 128 blocks): streams the lists 64 items at a time,
-//                     one lane per SYMBOL (size / amplitude / Huffman code, rle.c:9-35,99-123,
-//                     huffman.c:145-188), a wave prefix sum gives bit offsets, bits are OR-ed into an LDS
-//                     window and flushed as whole words.  ~30 registers, 8 waves per SIMD.
-//
-// Extra HBM traffic: 4 bytes per symbol written and read once (~25 MB per 8192^2 photo-like image, vs
-// 201 MB of pixels).  Lists are reserved at the worst case (65 items per block) so any content fits.
+// Extra HBM traffic: 4 bytes per symbol written and read once (~23 MB per 8192^2 photo-like image, vs 201 MB of pixels).
+// Lists are reserved at the worst case (65 items per block) so any content fits.
 #include <hip/hip_ext.h>
 #include "jpegamd_device.h"
 

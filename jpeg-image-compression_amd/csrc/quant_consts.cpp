@@ -9,8 +9,9 @@
 //
 //   E_ref    reference evaluation error: two roundings per product, one per sequential add, worst case over |p| <= 128
 //            with the actual |COS_LUT products| as weights
-//   E_mfma   accumulation error of the matrix pipe in ANY summation order (see derive_mfma_tables)
-//   E_split  residual of the bf16 split of the LUT products
+//   E_mfma   what the matrix pipe adds: its two accumulator chains are EXACT in any summation order (integer-valued binary16
+//            terms, every partial sum below 2^24 units -- see derive_mfma_tables), so only the ONE add that joins them rounds
+//   E_split  residual of the two-term split of the LUT products (2^-23 absolute per product)
 //   last     rounding of K/q, of the fma, and of the reference's final scale and division
 //
 // tests/test_host.py::test_mfma_constants_are_on_the_safe_side pins the stored constants against the oracle's arithmetic.

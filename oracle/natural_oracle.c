@@ -16,8 +16,8 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------
- * Tables (data; values must equal the reference's, tests/test_oracle_tables.py checks
- * them against the reference text when /root/reference is present).
+ * Tables (data; values must equal the reference's, tests/test_oracle.py::test_tables_equal_reference_text
+ * checks them against the reference text when /root/reference is present).
  * ---------------------------------------------------------------------------------- */
 
 /* Annex-K luminance table, raster order (src/core/jpeg_tables.c:3-12). */
