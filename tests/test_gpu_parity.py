@@ -231,6 +231,32 @@ def test_reference_sample_images(jpegamd, dev):
 
 
 @pytest.mark.gpu
+def test_profiling_ring_reports_the_kernels_own_durations(jpegamd, dev):
+    """jpegamd_encoder_set_profiling: every kernel carries its own begin / end events, so the three durations are positive,
+    their sum is below the first-begin-to-last-end span (launch gaps), and a 4x larger image takes longer."""
+    res = {}
+    for (w, h) in ((1024, 1024), (2048, 2048)):
+        enc = jpegamd.Encoder(w, h)
+        bmp = jpegamd.synth_bmp(w, h, 3, 0, 0)
+        img, px = upload_pixels(bmp, jpegamd, dev)
+        cap = 4096 + w * h
+        out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        size = torch.zeros(1, dtype=torch.int64, device=dev)
+        d = jpegamd.Encoder.image(px.data_ptr(), w, h, img.row_stride, True)
+        enc.set_profiling(8)
+        for _ in range(8):
+            enc.encode_async(d, out.data_ptr(), cap, size.data_ptr(), True, torch.cuda.current_stream().cuda_stream)
+        enc.finish()
+        prof = [enc.profile(s) for s in range(2, 8)]
+        for p in prof:
+            assert p.ns_transform > 0 and p.ns_entropy > 0 and p.ns_pack > 0
+            assert p.ns_transform + p.ns_entropy + p.ns_pack <= p.ns_total
+            assert p.ns_total < 5_000_000
+        res[w] = sum(p.ns_transform for p in prof) / len(prof)
+    assert res[2048] > res[1024]
+
+
+@pytest.mark.gpu
 def test_batched_launch_matches_the_oracle_image_by_image(jpegamd, oracle, dev):
     """jpegamd_encode_batch_async: several images of one geometry through ONE launch of each kernel.  DC prediction
     (rle.c:59-70), bit offsets and 0xFF stuffing (huffman.c:26-62) must restart with every image: each output equals the
