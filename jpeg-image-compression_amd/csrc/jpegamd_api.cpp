@@ -156,6 +156,8 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.exact, segs * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.edge, segs * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.ffin, segs * 8 * sizeof(uint16_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.grp_bits, (segs / kSegGroup + 2) * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.grp_ff, (segs / kSegGroup + 2) * 8 * sizeof(uint16_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->huff, 272 * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->prefix, 512));
     HIP_TRY_CREATE(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
@@ -179,7 +181,7 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
 extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (!e) return JPEGAMD_OK;
     if (e->pending) hipStreamSynchronize(e->last_stream);
-    hipFree(e->seg.words); hipFree(e->seg.bits); hipFree(e->seg.syms); hipFree(e->seg.exact); hipFree(e->seg.edge); hipFree(e->seg.ffin);
+    hipFree(e->seg.words); hipFree(e->seg.bits); hipFree(e->seg.syms); hipFree(e->seg.exact); hipFree(e->seg.edge); hipFree(e->seg.ffin); hipFree(e->seg.grp_bits); hipFree(e->seg.grp_ff);
     hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev);
     hipFree(e->tile_items); hipFree(e->tile_ctr); hipFree(e->stamps_dev);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
@@ -301,6 +303,7 @@ static int run_finalize_batch(JpegAmdEncoder *e, const ImageDesc &im, void *cons
     fa.seg = e->seg;
     fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
     fa.batch = im.batch;
+    fa.use_groups = (im.num_segs % kSegGroup == 0) ? 1 : 0;      // every image then starts on a group boundary
     for (int i = 0; i < im.batch; ++i) { fa.out[i] = (uint8_t *)outs_dev[i]; fa.out_size[i] = out_sizes_dev[i]; }
     fa.out_capacity = out_capacity; fa.stats = e->stats_dev;
     fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
@@ -309,12 +312,13 @@ static int run_finalize_batch(JpegAmdEncoder *e, const ImageDesc &im, void *cons
 }
 
 static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, uint64_t out_capacity, uint64_t *out_size_dev,
-                        int32_t with_container, hipStream_t stream, hipEvent_t *ev = nullptr) {
+                        int32_t with_container, hipStream_t stream, hipEvent_t *ev = nullptr, bool groups_valid = false) {
     FinalizeArgs fa;
     std::memset(&fa, 0, sizeof(fa));
     fa.seg = e->seg;
     fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
     fa.batch = 1;
+    fa.use_groups = groups_valid ? 1 : 0;       // (segments imported from other ranks have no group aggregates)
     fa.out[0] = (uint8_t *)out_dev; fa.out_capacity = out_capacity; fa.out_size[0] = out_size_dev; fa.stats = e->stats_dev;
     fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
     fa.write_eoi = with_container ? 1 : 0;
@@ -431,7 +435,8 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         ++e->calls;
     }
     if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
-    if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream, ev ? ev + 4 : nullptr,
+                     im.num_segs % kSegGroup == 0)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
     e->last_stream = stream;
     e->pending = true;

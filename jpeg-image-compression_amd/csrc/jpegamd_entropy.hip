@@ -104,9 +104,10 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         if (t < 32) s_huff[256 + t] = t == 13 ? table_entry(a.huff[0], 0u) /*EOB, symbol 0x00*/ : t < 16 ? table_entry(a.huff[256 + t], (uint32_t)t) : 0u;
     }
     __syncthreads();
+    __shared__ uint32_t s_gmeta[kWavesE][12];       // {bits, edge, ff[8]} of the workgroup's segments, for the group aggregate
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int seg = a.seg_begin + (int)blockIdx.x * kWavesE + wave;
-    if (seg >= a.seg_end) return;                   // wave-uniform: every wave below runs with all 64 lanes
+    if (seg < a.seg_end) {                          // wave-uniform: every wave in here runs with all 64 lanes
     uint32_t *win = s_win[wave];
 
     const int image = a.tiles_per_image ? seg / a.num_segs : 0;     // a batch: every image has num_segs segments and tiles_per_image tiles
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         return __builtin_amdgcn_raw_buffer_load_b64(irsrc, (int)voff, (int)p.soff, 0);
     };
 
-    uint32_t carry_bits = 0, wbase = 0, last_word = 0, first_word = 0, nzrl = 0;
+    uint32_t carry_bits = 0, wbase = 0, last_word = 0, first_word = 0, nzrl = 0, seg_edge = 0;
     bool flushed = false, any_ff = false;
     uint32_t ffc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // 0xFF census of the words [0, n) of the window; every word's successor is final (n == complete words and the rest is
@@ -309,10 +310,13 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         if (!flushed) first_word = win[0];
         if (done) last_word = win[done - 1];
         const uint32_t part = win[done];
-        if (lane == 0) {
+        {
             const uint32_t p = carry_bits & 31u;
             const uint32_t tail = p ? ((last_word << p) | (part >> (32u - p))) : last_word;
-            a.seg.edge[seg] = ((first_word >> 24) << 8) | (tail & 0x7Fu);    // first 8 bits | last 7 bits of the segment's string
+            seg_edge = ((first_word >> 24) << 8) | (tail & 0x7Fu);           // first 8 bits | last 7 bits of the segment's string
+        }
+        if (lane == 0) {
+            a.seg.edge[seg] = seg_edge;
             a.seg.bits[seg] = carry_bits;
             a.seg.syms[seg] = (uint32_t)seg_syms_items;                      // + ZRLs below
             a.seg.exact[seg] = (uint32_t)seg_exact;
@@ -328,7 +332,35 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
             if (lane == p) mine = t;
         }
     }
-    if (lane < 8) a.seg.ffin[(size_t)seg * 8 + lane] = (uint16_t)min(mine, 65535u);
+    if (lane < 8) {
+        a.seg.ffin[(size_t)seg * 8 + lane] = (uint16_t)min(mine, 65535u);
+        s_gmeta[wave][2 + lane] = min(mine, 65535u);
+    }
+    if (lane == 0) { s_gmeta[wave][0] = carry_bits; s_gmeta[wave][1] = seg_edge; }
+    } else if (lane < 12) {
+        s_gmeta[wave][lane] = 0u;                   // no segment: no bits, no ones at either end
+    }
+    // Group aggregate (SegArrays::grp_bits / grp_ff): lane i * 8 + p of wave 0 takes segment i of the group at group phase p.
+    __syncthreads();
+    static_assert(kWavesE == kSegGroup, "one workgroup of k_entropy = one segment group");
+    if (wave == 0) {
+        const int i = (lane >> 3) & 3, p = lane & 7;
+        uint32_t pre = 0;                           // bits of the group in front of segment i
+#pragma unroll
+        for (int j = 0; j < kWavesE - 1; ++j) pre += (j < i) ? s_gmeta[j][0] : 0u;
+        const uint32_t pi = ((uint32_t)p + pre) & 7u;
+        uint32_t c = s_gmeta[i][2 + pi];
+        if (pi && i > 0) {                          // the byte straddling the start of segment i (fin_owned_ff, jpegamd_finalize.hip)
+            const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(s_gmeta[i - 1][1] & 0x7Fu));
+            const uint32_t lead_ones = (uint32_t)__clz(~((s_gmeta[i][1] >> 8) << 24));
+            c += (tail_ones >= pi && lead_ones >= 8u - pi) ? 1u : 0u;
+        }
+        if (lane >= 32) c = 0u;
+        c += (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 8) * 4, (int)c);     // i: 0+1, 2+3 (lanes 0..7 and 16..23 matter)
+        c += (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 16) * 4, (int)c);    // lanes 0..7: all four
+        if (lane < 8) a.seg.grp_ff[(size_t)blockIdx.x * 8 + lane] = (uint16_t)min(c, 65535u);
+        if (lane == 0) a.seg.grp_bits[blockIdx.x] = s_gmeta[0][0] + s_gmeta[1][0] + s_gmeta[2][0] + s_gmeta[3][0];
+    }
 }
 
 int launch_entropy(const EntropyArgs &a, void *stream, void *const *ev) {

@@ -83,7 +83,8 @@ struct FinalizeView {
 };
 
 __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs args) {
-    __shared__ uint32_t s_wbits[kFinWaves], s_wff[kFinWaves];
+    __shared__ uint32_t s_wbits[2][kFinWaves], s_wff[2][kFinWaves];
+    static_assert(kFinWaves == 16, "the waves' totals are scanned in one DPP row");
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tid = (int)threadIdx.x;
     // A batch: workgroup -> (image, chunk inside the image); everything below works on that image alone (bit offsets, byte
     // phases and stuffing counts restart with every image).
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
         a.seg.words = args.seg.words + s0 * kSegCapWords;
         a.seg.bits = args.seg.bits + s0; a.seg.syms = args.seg.syms + s0; a.seg.exact = args.seg.exact + s0;
         a.seg.edge = args.seg.edge + s0; a.seg.ffin = args.seg.ffin + s0 * 8;
+        a.seg.grp_bits = args.seg.grp_bits + s0 / kSegGroup; a.seg.grp_ff = args.seg.grp_ff + (s0 / kSegGroup) * 8;   // (use_groups: s0 is a multiple)
         a.num_segs = args.num_segs;
         a.out = args.out[image]; a.out_capacity = args.out_capacity; a.out_size = args.out_size[image];
         a.stats = args.stats; a.prefix = args.prefix; a.prefix_len = args.prefix_len; a.write_eoi = args.write_eoi;
@@ -121,41 +123,58 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     // ---- 1. everything in front of this chunk: bits (64-bit) and owned 0xFF bytes of the segments [0, 16 g) -------------
     // Thread tid takes four consecutive segments per round of 4096; a block-wide exclusive scan of the bit counts gives
     // each of them its byte phase (the sum is needed mod 8 only, so 32-bit wrap-around is harmless).
+#ifdef JPEGAMD_FIN_SKIP_SCAN       // timing-only build: no scan over the predecessors (wrong offsets, every write still inside the output)
+    const int n_before = 0;
+#else
     const int n_before = g * kFinWaves;
+#endif
     unsigned long long chunk_b0 = 0, chunk_ff0 = 0;
+    const bool use_groups = args.use_groups != 0;
+    int par = 0;
     for (int base = 0; base < n_before; base += 4 * 64 * kFinWaves) {
         const int i = base + 4 * tid;
         uint4 b = make_uint4(0u, 0u, 0u, 0u), e = make_uint4(0u, 0u, 0u, 0u), f0 = b, f1 = b, f2 = b, f3 = b;
         uint32_t eprev = 0;
+        static_assert(kSegGroup == 4, "a thread's four segments are one group of k_entropy");
         if (i < n_before) {                                      // n_before is a multiple of 16: the four are all in front or none
-            b = *reinterpret_cast<const uint4 *>(a.seg.bits + i);
-            e = *reinterpret_cast<const uint4 *>(a.seg.edge + i);
+            if (use_groups) {                                    // the four as ONE entry: k_entropy's aggregate of its workgroup
+                b.x = a.seg.grp_bits[i / kSegGroup];
+                f0 = *reinterpret_cast<const uint4 *>(a.seg.grp_ff + (size_t)(i / kSegGroup) * 8);
+                e.x = a.seg.edge[i];
+            } else {
+                b = *reinterpret_cast<const uint4 *>(a.seg.bits + i);
+                e = *reinterpret_cast<const uint4 *>(a.seg.edge + i);
+                const uint4 *fp = reinterpret_cast<const uint4 *>(a.seg.ffin + (size_t)i * 8);
+                f0 = fp[0]; f1 = fp[1]; f2 = fp[2]; f3 = fp[3];
+            }
             if (i > 0) eprev = a.seg.edge[i - 1];
-            const uint4 *fp = reinterpret_cast<const uint4 *>(a.seg.ffin + (size_t)i * 8);
-            f0 = fp[0]; f1 = fp[1]; f2 = fp[2]; f3 = fp[3];
         }
         const uint32_t tot = b.x + b.y + b.z + b.w;
         const uint32_t incl = wave_incl_scan_u32(tot);
-        if (lane == 63) s_wbits[wave] = incl;
+        uint32_t *wb = s_wbits[par], *wf = s_wff[par];            // double-buffered by round: no barrier before the next round's writes
+        if (lane == 63) wb[wave] = incl;
         __syncthreads();
-        uint32_t woff = 0, round_bits = 0;
-#pragma unroll
-        for (int w = 0; w < kFinWaves; ++w) { const uint32_t t = s_wbits[w]; woff += w < wave ? t : 0u; round_bits += t; }
+        // the 16 waves' totals: every wave scans them in its own lanes 0..15 (one LDS read + a row scan, instead of 16 reads)
+        const uint32_t wt = lane < kFinWaves ? wb[lane] : 0u;
+        const uint32_t wincl = half_incl_scan_dpp(wt);            // kFinWaves == 16: one DPP row
+        const uint32_t round_bits = (uint32_t)__builtin_amdgcn_readlane((int)wincl, kFinWaves - 1);
+        const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wave);
         const uint32_t x0 = (uint32_t)chunk_b0 + woff + incl - tot;                 // bit offset of segment i, mod 2^32
         uint32_t ff = 0;
         if (i < n_before) {
-            ff = fin_owned_ff(f0, i, x0 & 7u, e.x, eprev) + fin_owned_ff(f1, i + 1, (x0 + b.x) & 7u, e.y, e.x) +
-                 fin_owned_ff(f2, i + 2, (x0 + b.x + b.y) & 7u, e.z, e.y) + fin_owned_ff(f3, i + 3, (x0 + b.x + b.y + b.z) & 7u, e.w, e.z);
+            ff = fin_owned_ff(f0, i, x0 & 7u, e.x, eprev);       // (a group's counts hold the bytes straddling its inner boundaries)
+            if (!use_groups)
+                ff += fin_owned_ff(f1, i + 1, (x0 + b.x) & 7u, e.y, e.x) + fin_owned_ff(f2, i + 2, (x0 + b.x + b.y) & 7u, e.z, e.y) +
+                      fin_owned_ff(f3, i + 3, (x0 + b.x + b.y + b.z) & 7u, e.w, e.z);
         }
         const uint32_t wff = (uint32_t)wave_sum_i32((int)ff);
-        if (lane == 0) s_wff[wave] = wff;
+        if (lane == 0) wf[wave] = wff;
         __syncthreads();
-        uint32_t round_ff = 0;
-#pragma unroll
-        for (int w = 0; w < kFinWaves; ++w) round_ff += s_wff[w];
+        const uint32_t ft = lane < kFinWaves ? wf[lane] : 0u;
+        const uint32_t round_ff = (uint32_t)__builtin_amdgcn_readlane((int)half_incl_scan_dpp(ft), kFinWaves - 1);
         chunk_b0 += round_bits;
         chunk_ff0 += round_ff;
-        __syncthreads();                                          // s_wbits / s_wff are rewritten by the next round
+        par ^= 1;
     }
     if (!have) return;                                            // no workgroup-wide synchronisation below
 

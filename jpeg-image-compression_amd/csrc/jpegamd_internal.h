@@ -88,7 +88,13 @@ struct SegArrays {
     uint32_t *exact;            // [num_segs] coefficients recomputed in exact order
     uint32_t *edge;             // [num_segs] (first 8 bits << 8) | last 7 bits: what the byte straddling two segments is made of
     uint16_t *ffin;             // [num_segs][8] 0xFF bytes lying wholly inside the segment when its first bit sits at byte phase p
+    // Per GROUP of kSegGroup consecutive segments (one workgroup of k_entropy), so that k_finalize's scan over everything in
+    // front of a chunk reads a quarter of the entries: the group's bits, and the 0xFF bytes its segments own when the group's
+    // first bit sits at byte phase p -- without the byte straddling the group's start (that needs the segment in front).
+    uint32_t *grp_bits;         // [ceil(num_segs / kSegGroup)]
+    uint16_t *grp_ff;           // [ceil(num_segs / kSegGroup)][8]
 };
+constexpr int kSegGroup = 4;
 
 struct TransformOutM {
     const MfmaTables *tables;   // device copy
@@ -120,6 +126,7 @@ struct FinalizeArgs {
     int32_t num_segs;               // per image
     int32_t num_chunks;             // per image: workgroups = batch * ceil(num_segs / 16)
     int32_t batch;
+    int32_t use_groups;             // the group aggregates are valid for these segments (whole images coded by k_entropy, num_segs % kSegGroup == 0)
     uint8_t *out[kMaxBatch];
     uint64_t out_capacity;          // of every output
     uint64_t *out_size[kMaxBatch];  // device
