@@ -98,23 +98,26 @@ __device__ __forceinline__ uint32_t ones8_starts(uint32_t cur, uint32_t nxt) {
 __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     __shared__ uint32_t s_huff[288];                // [0,256) AC, [256,272) DC sizes 0..15 (12: padding item, no code; 13: EOB)
     __shared__ uint32_t s_win[kWavesE][kSegBufWords + 8];
-    {
-        const int t = (int)threadIdx.x;
-        s_huff[t] = table_entry(a.huff[t], (uint32_t)t & 15u);
-        if (t < 32) s_huff[256 + t] = t == 13 ? table_entry(a.huff[0], 0u) /*EOB, symbol 0x00*/ : t < 16 ? table_entry(a.huff[256 + t], (uint32_t)t) : 0u;
-    }
-    __syncthreads();
     __shared__ uint32_t s_gmeta[kWavesE][12];       // {bits, edge, ff[8]} of the workgroup's segments, for the group aggregate
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int seg = a.seg_begin + (int)blockIdx.x * kWavesE + wave;
-    if (seg < a.seg_end) {                          // wave-uniform: every wave in here runs with all 64 lanes
+    // A wave without a segment (the last workgroup) walks the same code with an empty stream -- zero tiles, zero batches, its
+    // loads fall to the range checks, its stores are guarded by `have` -- because the workgroup meets at two barriers.
+    const bool have = seg < a.seg_end;
+    const int segc = have ? seg : a.seg_end - 1;
+    // Every load whose address does not depend on data goes out FIRST: the code-table words and the tiles' records.  (The table
+    // used to be built, behind its own load and a barrier, before the records were even requested: three serial round trips
+    // -- table, records, first items -- in front of the first symbol; now two.)
+    const int tcode = (int)threadIdx.x;
+    const uint32_t hword = a.huff[tcode];
+    const uint32_t hword2 = tcode == 13 ? a.huff[0] /*EOB, symbol 0x00*/ : tcode < 16 ? a.huff[256 + tcode] : 0u;
     uint32_t *win = s_win[wave];
 
-    const int image = a.tiles_per_image ? seg / a.num_segs : 0;     // a batch: every image has num_segs segments and tiles_per_image tiles
-    const int sl = seg - image * a.num_segs;
+    const int image = a.tiles_per_image ? segc / a.num_segs : 0;    // a batch: every image has num_segs segments and tiles_per_image tiles
+    const int sl = segc - image * a.num_segs;
     const int by = sl / a.segs_per_row;
     const int tx0 = (sl - by * a.segs_per_row) * kSegTiles;
-    const int ntiles = min(kSegTiles, a.tiles_per_row - tx0);
+    const int ntiles = have ? min(kSegTiles, a.tiles_per_row - tx0) : 0;
     const int tile_in_image = by * a.tiles_per_row + tx0;
     const int tile0 = image * a.tiles_per_image + tile_in_image;
 
@@ -222,6 +225,10 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
     make_plans(0u);
     Plan cur = fetch_plan(0u);
     auto nx = request(cur);
+    // the code table (its words were requested at the top), then the workgroup's first barrier, behind the first items' request
+    s_huff[tcode] = table_entry(hword, (uint32_t)tcode & 15u);
+    if (tcode < 32) s_huff[256 + tcode] = tcode == 13 ? table_entry(hword2, 0u) : tcode < 16 ? table_entry(hword2, (uint32_t)tcode) : 0u;
+    __syncthreads();
     uint32_t prev_b = 0;                                          // second item of the lane before lane 0: the previous batch's last item
 #pragma unroll 1
     for (uint32_t batch = 0; batch < nbatches; ++batch) {
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         const uint32_t done = (carry_bits >> 5) - wbase;
         const uint32_t nw = done + ((carry_bits & 31u) ? 1u : 0u);           // words holding bits; the window is zero behind them
         census(nw, flushed);
-        for (uint32_t j = (uint32_t)lane; j < nw; j += 64) segw[wbase + j] = win[j];
+        for (uint32_t j = (uint32_t)lane; j < nw; j += 64) segw[wbase + j] = win[j];     // (nw == 0 without a segment)
         if (!flushed) first_word = win[0];
         if (done) last_word = win[done - 1];
         const uint32_t part = win[done];
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
             const uint32_t tail = p ? ((last_word << p) | (part >> (32u - p))) : last_word;
             seg_edge = ((first_word >> 24) << 8) | (tail & 0x7Fu);           // first 8 bits | last 7 bits of the segment's string
         }
-        if (lane == 0) {
+        if (lane == 0 && have) {
             a.seg.edge[seg] = seg_edge;
             a.seg.bits[seg] = carry_bits;
             a.seg.syms[seg] = (uint32_t)seg_syms_items;                      // + ZRLs below
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         }
     }
     const uint32_t zsum = (uint32_t)wave_sum_i32((int)nzrl);
-    if (zsum && lane == 0) a.seg.syms[seg] = (uint32_t)seg_syms_items + zsum;
+    if (zsum && lane == 0 && have) a.seg.syms[seg] = (uint32_t)seg_syms_items + zsum;
     uint32_t mine = 0;                                                       // lane p < 8 stores the count of phase p
     if (any_ff) {
 #pragma unroll
@@ -333,13 +340,10 @@ __global__ __launch_bounds__(64 * kWavesE) void k_entropy(const EntropyArgs a) {
         }
     }
     if (lane < 8) {
-        a.seg.ffin[(size_t)seg * 8 + lane] = (uint16_t)min(mine, 65535u);
+        if (have) a.seg.ffin[(size_t)seg * 8 + lane] = (uint16_t)min(mine, 65535u);
         s_gmeta[wave][2 + lane] = min(mine, 65535u);
     }
-    if (lane == 0) { s_gmeta[wave][0] = carry_bits; s_gmeta[wave][1] = seg_edge; }
-    } else if (lane < 12) {
-        s_gmeta[wave][lane] = 0u;                   // no segment: no bits, no ones at either end
-    }
+    if (lane == 0) { s_gmeta[wave][0] = carry_bits; s_gmeta[wave][1] = have ? seg_edge : 0u; }   // (no segment: no bits, no ones at either end)
     // Group aggregate (SegArrays::grp_bits / grp_ff): lane i * 8 + p of wave 0 takes segment i of the group at group phase p.
     __syncthreads();
     static_assert(kWavesE == kSegGroup, "one workgroup of k_entropy = one segment group");
