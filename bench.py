@@ -7,9 +7,9 @@ Rank 0 prints ONE JSON line.
 
 Workloads (`--workload`, default `auto`):
   image8192  BASELINE.json configs[2], the config the metric and the roofline target are quoted on: 8192x8192 synthetic
-             24-bit BMPs.  By default a step codes FOUR of them (distinct pictures, 8 in rotation per rank: 1.6 GB > the
+             24-bit BMPs.  By default a step codes EIGHT of them (distinct pictures, 16 in rotation per rank: 3.2 GB > the
              256 MiB Infinity Cache) through ONE launch of each kernel (`--images-per-launch`, jpegamd_encode_batch_async):
-             the launch, prologue and drain costs of the three kernels are paid once per four images.  `--images-per-launch
+             the launch, prologue and drain costs of the three kernels are paid once per eight images.  `--images-per-launch
              1` is the single-image step of round 1 (3 rotating inputs); its kernel durations are also measured in every
              default run and reported as roofline.one_image_per_launch.
              This is what `auto` selects at EVERY N: the driver derives the scaling efficiency from the per-N values, so
@@ -72,7 +72,7 @@ def parse_args():
     ap.add_argument("--no-one-image-pass", action="store_true",
                     help="skip the one-image-per-launch comparison pass (kernel traces of the batched default: every launch then codes the same number of images)")
     ap.add_argument("--images-per-launch", type=int, default=0, choices=[0, 1, 2, 4, 8],
-                    help="images coded by ONE launch of each kernel (jpegamd_encode_batch_async); 0 = 4 for image8192 (that many images per step), 8 for batch4096")
+                    help="images coded by ONE launch of each kernel (jpegamd_encode_batch_async); 0 = 8 (image8192 then codes 8 images per step)")
     ap.add_argument("--roofline-idle-ms", type=float, default=250.0, help="idle time in front of the second single-stream roofline pass")
     ap.add_argument("--streams", type=int, default=4,
                     help="HIP streams (one encoder context each) the images alternate over; >1 lets the latency-bound tail "
@@ -207,7 +207,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     workload = args.workload if args.workload != "auto" else "image8192"
-    B = args.images_per_launch or (4 if workload == "image8192" else 8)
+    B = args.images_per_launch or 8
     if workload == "image8192":
         w, h, ips = args.width or 8192, args.height or 8192, B
         nrot = ROTATE if B == 1 else max(ROTATE, 2 * B)          # a launch reads B distinct pictures, two launches never the same ones

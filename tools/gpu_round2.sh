@@ -18,13 +18,13 @@ run driver20 --steps 20 --warmup 5 --no-cpu-baseline
 run s1 --streams 1 --steps 100 --warmup 10 --no-cpu-baseline
 run launch1 --images-per-launch 1 --no-cpu-baseline
 run launch1_s1 --images-per-launch 1 --streams 1 --steps 200 --warmup 20 --no-cpu-baseline
-run launch8 --images-per-launch 8 --streams 2 --steps 150 --warmup 20 --no-cpu-baseline
+run launch4 --images-per-launch 4 --no-cpu-baseline
 run q10 --quality 10 --steps 100 --warmup 10 --no-cpu-baseline
 run q90 --quality 90 --steps 100 --warmup 10 --no-cpu-baseline
 run kind1 --kind 1 --steps 50 --warmup 5 --no-cpu-baseline
 run batch4096 --workload batch4096 --force-gather --steps 50 --warmup 10 --no-cpu-baseline
 run batch4096_launch1 --workload batch4096 --images-per-launch 1 --force-gather --steps 50 --warmup 10 --no-cpu-baseline
-# kernel traces of the single-stream bench: the default (4 images per launch) and one image per launch
+# kernel traces of the single-stream bench: the default (8 images per launch) and one image per launch
 bash tools/gpu_trace.sh > $O/trace.txt 2>&1; grep -v "rocclr\|elementwise" $O/trace.txt
 cp gpurun_out/trace/default/t_kernel_stats.csv $O/kernel_stats.csv
 BENCH_EXTRA="--images-per-launch 1" bash tools/gpu_trace.sh > $O/trace_launch1.txt 2>&1; grep -v "rocclr\|elementwise" $O/trace_launch1.txt

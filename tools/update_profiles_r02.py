@@ -8,7 +8,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 r02, pmc, dst = ROOT / "gpurun_out" / "r02", ROOT / "gpurun_out" / "r02pmc", ROOT / "profiles"
-for name in ("default", "driver20", "s1", "launch1", "launch1_s1", "launch8", "q10", "q90", "kind1", "batch4096", "batch4096_launch1"):
+for name in ("default", "driver20", "s1", "launch1", "launch1_s1", "launch4", "q10", "q90", "kind1", "batch4096", "batch4096_launch1"):
     f = r02 / f"bench_{name}.json"
     if f.exists():
         shutil.copy(f, dst / f"r02_bench_{name}.json")
@@ -18,7 +18,7 @@ for tag, flags in (("", ""), ("_launch1", " --images-per-launch 1")):
     if (r02 / f"trace{tag}.txt").exists():
         (dst / f"r02_kernel_trace_summary{tag}.txt").write_text(
             f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1 --steps 100 --warmup 10 --no-cpu-baseline --no-one-image-pass{flags}  (tools/gpu_trace.sh, tools/trace_gaps.py)\n"
-            + ("# default: 4 images of 8192^2 per launch -- divide a duration by 4 for the per-image figure\n" if not tag else "")
+            + ("# default: 8 images of 8192^2 per launch -- divide a duration by 8 for the per-image figure\n" if not tag else "")
             + "".join(l for l in (r02 / f"trace{tag}.txt").read_text().splitlines(True) if "rocclr" not in l and "elementwise" not in l))
 
 vals = {}
