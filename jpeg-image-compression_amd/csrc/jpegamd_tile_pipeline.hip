@@ -149,6 +149,9 @@ constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket count
 constexpr int kCopyStores = JPEGAMD_COPY_STORES;                 // 16-byte-per-lane stores that close every iteration
 constexpr int kStageItems = kCopyStores * 256 - 1;               // longest list built in LDS (+ its padding item)
 static_assert(kCopyStores * 256 <= 8 * 132, "the staged list lives in the tile's luma buffer");
+#ifndef JPEGAMD_TILE_STATIC
+#define JPEGAMD_TILE_STATIC 0
+#endif
 #ifndef JPEGAMD_TILE_STEAL
 #define JPEGAMD_TILE_STEAL 0          // partner groups a wave may draw tiles from once its own group is dry
 #endif
@@ -302,7 +305,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     // This launch's counters were zeroed by the previous launch on this context; zero the next launch's (the other set).
     if (bid == 0 && threadIdx.x < kTileGroups) out.tile_ctr_next[threadIdx.x * 32] = 0u;   // all of them: the next launch may form more groups
     const int first = (bid >> sch.grp_shift) * kWavesT + wave;
+#if JPEGAMD_TILE_STATIC            // experiment: no tickets, wave w of a group takes the group's tiles w, w + waves, w + 2 waves, ...
+    const auto ticket = [&]() -> uint32_t { return 0u; };
+#else
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
+#endif
     struct TileGeo { int img, by, tbx0, nblk, bx; bool interior; };
     const auto geo = [&](int tile) {
         TileGeo g;
@@ -480,7 +487,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         if (!active) flagbits = 0u;
         TSTAMP(4);   // quantise
 #if JPEGAMD_PREFETCH_EARLY       // ticket collected and the next tile's rows requested HERE: in flight behind the exact-order, count and append phases
+#if JPEGAMD_TILE_STATIC
+        int nxt = li + cur_waves + (int)(ticket_v & 0u);
+#else
         int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
+#endif
 #if JPEGAMD_TILE_STEAL
         // Own group dry: draw from a partner group's counter (its waves cannot tell).  The ticket is waited for here, once or
         // twice per wave at the very end of its work; a failed draw ends the wave.
@@ -598,7 +609,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // the wait for it then covers no younger memory operation (built with the atomic optimizer off -- its
         // expansion reads the result back, and waits for vmcnt(0), right behind the atomic).
 #if !JPEGAMD_PREFETCH_EARLY
+#if JPEGAMD_TILE_STATIC
+        int nxt = li + cur_waves + (int)(ticket_v & 0u);
+#else
         int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
+#endif
 #if JPEGAMD_TILE_STEAL
         // Own group dry: draw from a partner group's counter (its waves cannot tell).  The ticket is waited for here, once or
         // twice per wave at the very end of its work; a failed draw ends the wave.
