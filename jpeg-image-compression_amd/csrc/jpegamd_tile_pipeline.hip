@@ -115,46 +115,16 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 #ifndef JPEGAMD_TILE_GROUPS
 #define JPEGAMD_TILE_GROUPS 64
 #endif
-#ifndef JPEGAMD_ITEM_AUX
-#define JPEGAMD_ITEM_AUX 0           // cache policy bits of the item stores (0 default, 2 nt, 16 sc1)
-#endif
 constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket counters (one cache line each) of the dynamic tile hand-out
 #ifndef JPEGAMD_TILE_WAVES
 #define JPEGAMD_TILE_WAVES 4
 #endif
-#ifndef JPEGAMD_TICKET_EARLY
-#define JPEGAMD_TICKET_EARLY 2       // where the next tile's ticket is requested: 0 before the exact-order phase, 1 at the top of the iteration, 2 behind the MFMAs
-#endif
-#ifndef JPEGAMD_FLAG_MINTREE
-#define JPEGAMD_FLAG_MINTREE 1
-#endif
-#ifndef JPEGAMD_BIAS_VGPR
-#define JPEGAMD_BIAS_VGPR 1
-#endif
-#ifndef JPEGAMD_THR_REGS
-#define JPEGAMD_THR_REGS 0
-#endif
-#ifndef JPEGAMD_APPEND_ASM
-#define JPEGAMD_APPEND_ASM 1
-#endif
-#ifndef JPEGAMD_PREFETCH_EARLY
-#define JPEGAMD_PREFETCH_EARLY 0
-#endif
 #ifndef JPEGAMD_COPY_STORES
 #define JPEGAMD_COPY_STORES 4
-#endif
-#ifndef JPEGAMD_COPY_AUX
-#define JPEGAMD_COPY_AUX 0           // cache policy bits of the closing stores
 #endif
 constexpr int kCopyStores = JPEGAMD_COPY_STORES;                 // 16-byte-per-lane stores that close every iteration
 constexpr int kStageItems = kCopyStores * 256 - 1;               // longest list built in LDS (+ its padding item)
 static_assert(kCopyStores * 256 <= 8 * 132, "the staged list lives in the tile's luma buffer");
-#ifndef JPEGAMD_TILE_STATIC
-#define JPEGAMD_TILE_STATIC 0
-#endif
-#ifndef JPEGAMD_TILE_STEAL
-#define JPEGAMD_TILE_STEAL 0          // partner groups a wave may draw tiles from once its own group is dry
-#endif
 
 struct TileSched {            // division-free launch geometry, filled by launch_tile_transform
     int32_t grp_shift;        // workgroups form 1 << grp_shift ticket groups (blockIdx & mask)
@@ -235,34 +205,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
     const int h = lane >> 5, b = lane & 31;
     float bias;                                 // in a VGPR: v_fma_f32 with three VGPR operands issues in 2 cycles, with an SGPR operand in 4 (profiles/r02_issue_model_forms.txt)
-#if JPEGAMD_BIAS_VGPR
     asm volatile("v_mov_b32 %0, %1" : "=v"(bias) : "s"(out.tables->bias));
-#else
-    bias = out.tables->bias;
-#endif
     const LumaWeights lw = luma_weights(im.weights);
     const uint32_t luma_kc = 0xFFFF8000u;
     const float2 *sq_lane = &s_q[8 * h];
-#if JPEGAMD_THR_REGS
-    // The lane's group thresholds live in registers: every one read from LDS inside the loop is a round trip the wave waits
-    // for right in front of a wave-wide branch.
-    float zero_thr[4], flag_thr[4];
-    {   // one block: the results are not there before the wait, and the compiler must not touch them in between
-        const uint32_t ga = (uint32_t)(uintptr_t)&s_grp[h];
-        asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:8\n\tds_read_b32 %2, %8 offset:16\n\tds_read_b32 %3, %8 offset:24\n\t"
-                     "ds_read_b32 %4, %8 offset:32\n\tds_read_b32 %5, %8 offset:40\n\tds_read_b32 %6, %8 offset:48\n\tds_read_b32 %7, %8 offset:56\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(zero_thr[0]), "=&v"(zero_thr[1]), "=&v"(zero_thr[2]), "=&v"(zero_thr[3]),
-                       "=&v"(flag_thr[0]), "=&v"(flag_thr[1]), "=&v"(flag_thr[2]), "=&v"(flag_thr[3])
-                     : "v"(ga) : "memory");
-    }
-#define zero_thr(G) zero_thr[G]
-#define flag_thr(G) flag_thr[G]
-#else
-    const float *zthr_lds = &s_grp[h];
-#define zero_thr(G) zthr_lds[2 * (G)]
-#define flag_thr(G) zthr_lds[8 + 2 * (G)]
-#endif
+    const float *zthr_lds = &s_grp[h];                             // zero threshold of group G: [2 G], its largest tie threshold: [8 + 2 G]
 
     // Persistent waves: tile = first, first + stride, ...  The matrix image is loaded once per workgroup and the
     // NEXT tile's pixel rows are requested as soon as the current ones are converted, so their HBM latency
@@ -293,10 +240,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const int chunks = full_steps + ((rem > 0 && ((g + full_steps) & gmask) < rem) ? 1 : 0);
         return chunks * kWavesT - (g == last_owner ? nchunks * kWavesT - ntl : 0);
     };
-    // The group this wave currently draws tiles from: its own, then (JPEGAMD_TILE_STEAL levels) the groups grp ^ 1, grp ^ 2, ...
-    // -- members of other XCDs (XCD = workgroup % 8 = grp % 8), whose clocks differ by up to 10 % under this load.
+    // (Drawing from partner groups on other XCDs once the own group is dry was tried, 1-3 levels deep: no gain -- the spread
+    // INSIDE a group, one tile-time, dominates.  profiles/r02_notes_experiments.txt)
     int cur_grp = grp, cur_hi = tiles_of(grp), cur_waves = waves_of(grp);
-    [[maybe_unused]] int steal_level = 0;
     const auto to_tile = [&](int li) {
         const int k = li / kWavesT;
         return im.tile_begin + (((k << sch.grp_shift) + ((cur_grp + k) & gmask)) * kWavesT) + (li % kWavesT);
@@ -305,11 +251,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     // This launch's counters were zeroed by the previous launch on this context; zero the next launch's (the other set).
     if (bid == 0 && threadIdx.x < kTileGroups) out.tile_ctr_next[threadIdx.x * 32] = 0u;   // all of them: the next launch may form more groups
     const int first = (bid >> sch.grp_shift) * kWavesT + wave;
-#if JPEGAMD_TILE_STATIC            // experiment: no tickets, wave w of a group takes the group's tiles w, w + waves, w + 2 waves, ...
-    const auto ticket = [&]() -> uint32_t { return 0u; };
-#else
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
-#endif
     struct TileGeo { int img, by, tbx0, nblk, bx; bool interior; };
     const auto geo = [&](int tile) {
         TileGeo g;
@@ -332,12 +274,15 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     // Interior tiles: a scalar base (lowest-address row of the tile's 8, first block) plus 32-bit lane offsets --
     // one multiply-add and three adds per tile instead of eight 64-bit multiply-adds (quarter-rate instructions).
     // Lane (h, b) reads picture rows by*8 + 2s + h; in a bottom-up BMP those lie at DEscending addresses (bmp_handler.c:109).
-    const uint32_t row_term = (uint32_t)(im.bottom_up ? 7 - h : h) * (uint32_t)im.row_stride;
+    // (the lane's row term, (bottom_up ? 7 - h : h) * row_stride, is recomputed per tile from an opaque copy of h: as a loop
+    //  invariant it was spilled, and its reload sat, behind a vmcnt(0), right in front of the row requests)
     const int32_t row_step = im.bottom_up ? -2 * im.row_stride : 2 * im.row_stride;
     const auto request_rows = [&](const TileGeo &g, RawRow (&raw)[4]) {
         const int row_low = im.bottom_up ? im.height - 8 - g.by * 8 : g.by * 8;
         const uint8_t *tb = im.batch_pixels[g.img] + (size_t)row_low * (size_t)im.row_stride + 24 * (size_t)g.tbx0;
-        uint32_t off = __umul24((uint32_t)(g.bx - g.tbx0), 24u) + row_term;
+        uint32_t hh = (uint32_t)h;
+        asm volatile("" : "+v"(hh));
+        uint32_t off = __umul24((uint32_t)(g.bx - g.tbx0), 24u) + __umul24(im.bottom_up ? 7u - hh : hh, (uint32_t)im.row_stride);   // row_stride < 2^24
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             raw[s] = load_raw_row(reinterpret_cast<const uint32_t *>(tb + off));
@@ -361,9 +306,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const bool active = b < nblk, interior = tg.interior;
         int nexact = 0;
         TSTAMP(0);   // loop overhead / geometry
-#if JPEGAMD_TICKET_EARLY == 1
-        const uint32_t ticket_v = ticket();
-#endif
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         f16x8 bfrag[4];
         if (interior) {                        // rows requested one iteration ago, behind the ticket (below)
@@ -424,9 +366,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
 
         TSTAMP(3);   // MFMA
-#if JPEGAMD_TICKET_EARLY == 2
         const uint32_t ticket_v = ticket();
-#endif
         // ---- 3. quantise with the guard band, one GROUP of 8 sites at a time -----------------------
         // Site s = 16H + r of lane (h, b) holds zigzag position 16 * (s >> 3) + 8 * h + (s & 7): group G = s >> 3
         // covers zigzag 16G .. 16G + 15 across the two lanes of a block.  Every instruction of any wave costs one
@@ -450,7 +390,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 float m = fmaxf(fabsf(a8[0]), fabsf(a8[1]));
 #pragma unroll
                 for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(a8[j]));
-                gact[G] = __ballot(m >= zero_thr(G)) != 0ull;
+                gact[G] = __ballot(m >= zthr_lds[2 * G]) != 0ull;
             }
             if (gact[G]) {
                 float fr[8], th[8];
@@ -466,7 +406,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 // Flags are rare (0.4 per tile): one min tree over the fractions against the group's largest threshold decides
                 // for the whole wave whether the per-site compares (16 instructions) are needed at all.
                 const float fmin8 = fminf(fminf(__builtin_fminf(fr[0], fminf(fr[1], fr[2])), fminf(fr[3], fminf(fr[4], fr[5]))), fminf(fr[6], fr[7]));
-                if (!JPEGAMD_FLAG_MINTREE || __ballot(fmin8 <= flag_thr(G)) != 0ull)
+                if (__ballot(fmin8 <= zthr_lds[8 + 2 * G]) != 0ull)
                     flagbits |= shift_in_le8(0u, fr, th) << (8 * G);        // bit j: site 8G + j is within delta of a tie
             } else if (kTaps) {
 #pragma unroll
@@ -486,47 +426,11 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         }
         if (!active) flagbits = 0u;
         TSTAMP(4);   // quantise
-#if JPEGAMD_PREFETCH_EARLY       // ticket collected and the next tile's rows requested HERE: in flight behind the exact-order, count and append phases
-#if JPEGAMD_TILE_STATIC
-        int nxt = li + cur_waves + (int)(ticket_v & 0u);
-#else
-        int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
-#endif
-#if JPEGAMD_TILE_STEAL
-        // Own group dry: draw from a partner group's counter (its waves cannot tell).  The ticket is waited for here, once or
-        // twice per wave at the very end of its work; a failed draw ends the wave.
-        while (nxt >= cur_hi && steal_level < JPEGAMD_TILE_STEAL && (1 << steal_level) < groups) {
-            cur_grp = grp ^ (1 << steal_level);
-            ++steal_level;
-            cur_hi = tiles_of(cur_grp);
-            cur_waves = waves_of(cur_grp);
-            ctr = out.tile_ctr + cur_grp * 32;
-            nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket());
-        }
-#endif
-        TileGeo tg_next = tg;
-        int tile_next = tile;
-        if (nxt < cur_hi) { tile_next = to_tile(nxt); tg_next = geo(tile_next); }
-        // The next tile's pixel rows: 8 loads, in flight behind the appends.  vmcnt retires in issue order, so the wait at
-        // the top of the loop must not have to count a VARYING number of younger stores: whatever path the appends take,
-        // exactly kCopyStores stores close the iteration (the compiler then waits for vmcnt(kCopyStores), not 0).
-        if (nxt < cur_hi && tg_next.interior) {
-            request_rows(tg_next, raw);
-        } else {                               // (defined on every path -- by an empty asm, i.e. no instruction: else the old rows stay
-#pragma unroll                                 //  live through the whole iteration, and zeroing them was hoisted in front of the branch)
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 6; ++i) asm volatile("" : "=v"(raw[s].d[i]));
-        }
-#endif
 
         // The ticket for this wave's NEXT tile is requested here and collected before the appends (its latency hides
         // behind the exact-order and count phases).  Round 1 asked one whole iteration earlier, for the tile after next:
         // every wave then sat on a reserved, unstarted tile when its group ran dry, and the last waves of a group
         // finished two tile-times (11 us of 58) after the first (profiles/r02_stamps_interleaved.txt).
-#if !JPEGAMD_TICKET_EARLY
-        const uint32_t ticket_v = ticket();
-#endif
         // ---- 4. exact-order recomputation of flagged coefficients ------------------------------
         uint64_t exact_mask = 0;
         unsigned long long fm = __ballot(flagbits != 0u);
@@ -608,24 +512,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         // The ticket requested at the top of the iteration is collected here, BEFORE the item stores are issued:
         // the wait for it then covers no younger memory operation (built with the atomic optimizer off -- its
         // expansion reads the result back, and waits for vmcnt(0), right behind the atomic).
-#if !JPEGAMD_PREFETCH_EARLY
-#if JPEGAMD_TILE_STATIC
-        int nxt = li + cur_waves + (int)(ticket_v & 0u);
-#else
         int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
-#endif
-#if JPEGAMD_TILE_STEAL
-        // Own group dry: draw from a partner group's counter (its waves cannot tell).  The ticket is waited for here, once or
-        // twice per wave at the very end of its work; a failed draw ends the wave.
-        while (nxt >= cur_hi && steal_level < JPEGAMD_TILE_STEAL && (1 << steal_level) < groups) {
-            cur_grp = grp ^ (1 << steal_level);
-            ++steal_level;
-            cur_hi = tiles_of(cur_grp);
-            cur_waves = waves_of(cur_grp);
-            ctr = out.tile_ctr + cur_grp * 32;
-            nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket());
-        }
-#endif
         TileGeo tg_next = tg;
         int tile_next = tile;
         if (nxt < cur_hi) { tile_next = to_tile(nxt); tg_next = geo(tile_next); }
@@ -640,7 +527,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll
                 for (int i = 0; i < 6; ++i) asm volatile("" : "=v"(raw[s].d[i]));
         }
-#endif
         // ---- 6. append the items (from word 0 of the tile's list) ----
         // Per item: one SDWA add writes the zigzag position into the upper half of the value's own register, one write, one
         // offset increment.  Up to kStageItems items the list is built in LDS (the tile's luma there is dead by now) and leaves
@@ -650,7 +536,6 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const bool staged = t_all <= (uint32_t)kStageItems;
         uint32_t *stage = &s_pix[wave][0];
         if (staged) {
-#if JPEGAMD_APPEND_ASM
             if (active) {
                 const uint32_t stage_addr = (uint32_t)(uintptr_t)stage;      // LDS byte address (the low 32 bits of the flat one)
                 uint32_t addr = 0;
@@ -685,40 +570,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the asm writes are invisible to the compiler's counters
-#else
-            if (active) {
-                uint32_t off = 0;
-#pragma unroll
-                for (int G = 0; G < 4; ++G) {
-                    if (!gact[G]) continue;
-                    off = blk_base + ((starts >> (8 * G)) & 0xFFu);
-                    const uint32_t zg = (uint32_t)(16 * G + 8 * h);
-                    if (G == 0 && h == 0) { stage[off] = dc_item; off += 1u; }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
-                        if (v != 0) {
-                            uint32_t item = (uint32_t)v;
-                            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-                                : "+v"(item) : "v"(zg), "n"(j));
-                            stage[off] = item;
-                            off += 1u;
-                        }
-                    }
-                }
-                if (eob) {
-                    if (!gact[3]) off = blk_base + (starts >> 24);
-                    stage[off] = kItEobValue;
-                }
-            }
-#endif
             if (lane == 0 && (t_all & 1u)) stage[t_all] = kItPadValue;  // k_entropy's lanes take two items each: even count per list
         } else {
-#ifdef JPEGAMD_NO_ITEM_STORE           // timing-only build: zero records, the range check drops every item store (stream, waits unchanged)
-            const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, 0, 0x00020000);
-#else
             const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, kTileRecord * 4, 0x00020000);
-#endif
             if (active) {
                 uint32_t off = 0;
 #pragma unroll
@@ -726,7 +580,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                     if (!gact[G]) continue;
                     off = (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
                     const uint32_t zg = (uint32_t)(16 * G + 8 * h);
-                    if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, JPEGAMD_ITEM_AUX); off += 4u; }
+                    if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, 0); off += 4u; }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
@@ -734,14 +588,14 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                             uint32_t item = (uint32_t)v;
                             asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
                                 : "+v"(item) : "v"(zg), "n"(j));
-                            __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, 0);
                             off += 4u;
                         }
                     }
                 }
                 if (eob) {
                     if (!gact[3]) off = (blk_base + (starts >> 24)) * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b32(kItEobValue, lrsrc, off, 0, JPEGAMD_ITEM_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(kItEobValue, lrsrc, off, 0, 0);
                 }
             }
             if (lane == 0 && (t_all & 1u)) list[t_all] = kItPadValue;
@@ -757,7 +611,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll
             for (int i = 0; i < kCopyStores; ++i) {
                 const u32x4 piece = *reinterpret_cast<const u32x4 *>(&stage[i * 256 + lane * 4]);
-                __builtin_amdgcn_raw_buffer_store_b128(piece, crsrc, (uint32_t)(i * 1024 + lane * 16), 0, JPEGAMD_COPY_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(piece, crsrc, (uint32_t)(i * 1024 + lane * 16), 0, 0);
             }
         }
 #undef JPEGAMD_ACC
