@@ -94,7 +94,7 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 
 
 // In-kernel phase stamps (diagnostic builds only: -DJPEGAMD_STAMPS; the shipped kernel executes none).
-// Unlike the fused kernel's stamps these do NOT drain vmcnt, so the prefetch / store overlap stays as shipped;
+// The stamps do NOT drain vmcnt, so the prefetch / store overlap stays as shipped;
 // a phase is charged with whatever its own s_waitcnt instructions wait for.
 #ifdef JPEGAMD_STAMPS
 #define TSTAMP(i)                                                                             \

@@ -120,14 +120,15 @@ constexpr double kPmax = 128.0;
 
 // ---- matrix-pipe tables ----------------------------------------------------------------------
 // out_z = sum_p Kmat[c][p] * pix[p], Kmat[c][p] = COS_LUT[x][u] * COS_LUT[y][v] (exact product of the two float32
-// literals), computed by 8 v_mfma_f32_32x32x16_f16 per chain: kMfmaScale * Kmat = hi + lo in binary16 (22 significant
-// bits; the scale 2^14 keeps lo out of the subnormal range), pixels (int8) exact in binary16, so every product is exact
-// in f32 and only accumulation rounds.  Round 1 used three bf16 terms (24 bits, 12 MFMAs per chain): the third term bought
-// a residual of 2^-25 |K| where 2^-23 |K| is still < 10 % of the reference's own evaluation error E_ref.
-// Guard band: E_mfma = 2 * 16u * sum_m (|acc before MFMA m| + S_m),   S_m = 128 * sum_{p in k-step m} |term|
-// holds for ANY order in which the hardware adds the 16 products of one instruction to the accumulator (the factor 2
-// covers truncating adders); plus the split residual 128*sum|Kmat - (hi+lo)/scale|, taken as the larger of "lo kept" and
-// "lo flushed to zero where it is a binary16 subnormal" (never the case at this scale unless the residual is ~0 anyway).
+// literals), computed by two chains of 4 v_mfma_f32_32x32x16_f16 per row half: Kmat = hi 2^-11 + lo 2^-22 with INTEGER
+// hi = round(2^11 Kmat) (|hi| <= 2048) and lo = round(2^22 (Kmat - hi 2^-11)) (|lo| <= 1024); the hi chain's A entries
+// are hi, the lo chain's are lo 2^-11 (both exact in binary16), pixels (int8) exact in binary16.  With |pix| <= 128 every
+// product and every partial sum of a chain is a multiple of the chain's unit (1, resp. 2^-11) below 2^24 units, so the
+// float32 accumulation is EXACT in any order the hardware adds; the kernel joins the chains with one float add:
+// acc = kMfmaScale * (LUT sum with Kmat replaced by hi 2^-11 + lo 2^-22), one rounding.  derive_mfma_tables verifies the
+// representability and the 2^24 bounds (split_ok) and falls back to "flag everything" if they ever failed.
+// (History: round 1 used three bf16 terms in one accumulator, round 2's first kernel two binary16 terms in one accumulator
+// with E_mfma = 2 * 16u * sum_m (|acc before MFMA m| + S_m): 2.3 x the reference's own evaluation error E_ref.)
 namespace {
 // double -> IEEE binary16 bits, round to nearest even, subnormals kept; |x| < 65520
 uint16_t to_f16(double x) {
