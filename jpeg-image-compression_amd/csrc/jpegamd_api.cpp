@@ -1,6 +1,6 @@
 // jpegamd_api.cpp -- C-ABI host layer over the HIP kernels (include/jpeg_compression.h).
 //
-// Level 1 (jpegamd_*): device-resident, stream-ordered encode: k_tile_transform -> k_entropy -> k_finalize.
+// Level 1 (jpegamd_*): device-resident, stream-ordered encode: k_tile_encode -> k_segment_merge -> k_finalize.
 // Level 2 (JpegCompression_Init / convertToJpeg): the reference's accelerator boundary
 //          (dsp_port/jpeg_compression/src/jpeg_compression.c:6-33,35-216).
 // There is no CPU fallback: without a HIP device every compute entry fails.
@@ -39,7 +39,7 @@ struct JpegAmdEncoder {
     ScanStats mirror;            // host copy of stats_dev, fetched by finish()
     MfmaTables *tables_dev = nullptr;
     MfmaTables *tables_host = nullptr;          // this context's own staging copy (contexts may be driven from different threads)
-    uint32_t *tile_items = nullptr, *tile_ctr = nullptr;
+    uint32_t *tile_str = nullptr, *tile_ctr = nullptr, *code_tab = nullptr;
     int ctr_set = 0;                    // which half of tile_ctr the next k_tile_transform launch uses
     unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
     // cached constants
@@ -163,7 +163,8 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY_CREATE(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
     HIP_TRY_CREATE(hipMemset(e->stats_dev, 0, sizeof(ScanStats)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
-    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_items, (size_t)e->max_tiles * kTileItemCap * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_str, (size_t)e->max_tiles * kTileStrCap * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->code_tab, kCodeWords * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->tile_ctr, 2 * 64 * 128));      // two sets of ticket-group cache lines, used alternately
     HIP_TRY_CREATE(hipMemset(e->tile_ctr, 0, 2 * 64 * 128));
     if (std::getenv("JPEGAMD_STAMPS")) {
@@ -174,6 +175,11 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     uint32_t words[272];
     build_huffman_words(words);
     HIP_TRY_CREATE(hipMemcpy(e->huff, words, sizeof(words), hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> ct(kCodeWords);
+        build_code_table(ct.data());
+        HIP_TRY_CREATE(hipMemcpy(e->code_tab, ct.data(), kCodeWords * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     *out = e;
     return JPEGAMD_OK;
 }
@@ -183,7 +189,7 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (e->pending) hipStreamSynchronize(e->last_stream);
     hipFree(e->seg.words); hipFree(e->seg.bits); hipFree(e->seg.syms); hipFree(e->seg.exact); hipFree(e->seg.edge); hipFree(e->seg.ffin); hipFree(e->seg.grp_bits); hipFree(e->seg.grp_ff);
     hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev);
-    hipFree(e->tile_items); hipFree(e->tile_ctr); hipFree(e->stamps_dev);
+    hipFree(e->tile_str); hipFree(e->code_tab); hipFree(e->tile_ctr); hipFree(e->stamps_dev);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e->tables_host;
     delete e;
@@ -272,28 +278,29 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     return JPEGAMD_OK;
 }
 
-// k_tile_transform, then k_entropy; `mid` (optional) is recorded between the two.
+// k_tile_encode, then k_segment_merge.
 static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
                                         void *stream, hipEvent_t *ev = nullptr /*4: begin/end of the two kernels*/) {
     TransformOutM to;
     std::memset(&to, 0, sizeof(to));
     to.tables = e->tables_dev; to.stamps = e->stamps_dev;
     to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
-    to.tile_items = e->tile_items;
+    to.tile_str = e->tile_str; to.code_tab = e->code_tab;
     // Launches on one context are stream-ordered by contract (they share the scratch): launch i draws tickets from set
     // i % 2 and zeroes the other one for launch i + 1.
     to.tile_ctr = e->tile_ctr + (e->ctr_set ? 64 * 32 : 0);
     to.tile_ctr_next = e->tile_ctr + (e->ctr_set ? 0 : 64 * 32);
     if (int err = launch_tile_transform(im, to, taps, stream, (ev && !taps) ? (void *const *)ev : nullptr)) return err;
     if (im.tile_end > im.tile_begin) e->ctr_set ^= 1;      // (an empty range launches nothing)
-    EntropyArgs ea;
+    MergeArgs ea;
     std::memset(&ea, 0, sizeof(ea));
-    ea.tile_items = e->tile_items;
+    ea.tile_str = e->tile_str;
     ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
     ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
     ea.tiles_per_image = im.batch > 1 ? im.num_tiles : 0;
     ea.seg = e->seg;
-    return launch_entropy(ea, stream, ev ? (void *const *)(ev + 2) : nullptr);
+    ea.status = &e->stats_dev->status;
+    return launch_segment_merge(ea, stream, ev ? (void *const *)(ev + 2) : nullptr);
 }
 
 static int run_finalize_batch(JpegAmdEncoder *e, const ImageDesc &im, void *const *outs_dev, uint64_t out_capacity,
@@ -510,6 +517,7 @@ extern "C" int32_t jpegamd_encoder_finish(JpegAmdEncoder *e, JpegAmdStats *stats
             if (rc) return rc;
         }
     }
+    if (e->mirror.status & 2u) return JPEGAMD_ERR_RLE_CAPACITY;     // a tile record outside its reservation (corrupt scratch)
     return (e->mirror.status & 1u) ? JPEGAMD_ERR_HUFF_CAPACITY : JPEGAMD_OK;
 }
 

@@ -26,22 +26,39 @@ constexpr int kSegCapWords = ((kSegBlocks * kMaxBlockBits + 31) / 32 + 1 + 63) /
 constexpr int kAFragWords = 2 * 2 * 4 * 64 * 4;                      // [term][chain][kstep][lane] x 8 binary16 = 16 KiB
 constexpr float kMfmaScale = 2048.0f;                                // the accumulator chains hold kMfmaScale * LUT sum (hi chain + lo chain)
 
-// Per-tile symbol lists in HBM (k_tile_transform -> k_entropy).  A list holds the tile's items from word 0, in block order
-// then zigzag order; a block's run is: DC item, non-zero AC items, EOB item (kItEobValue) unless zigzag 63 is non-zero.
-// The count is padded to an EVEN number with one padding item (kItPadValue), so that k_entropy's lanes (two items each) never straddle
-// two lists.  The list's last 4 words are the tile record {items (unpadded), DC of the last block, exact-path count, 0}.
-constexpr uint32_t kItDc = 0x80000000u;         // item is a DC difference
-constexpr uint32_t kItFirst = 0x40000000u;      // ... of the first block of its tile: the value is the ABSOLUTE DC
-constexpr uint32_t kItNop = 0x20000000u;        // marks the padding item
-// The padding item: a DC-flagged item of size 12 -- a size the Huffman table has no code for -- whose amplitude bits are all
-// zero (value -4095: amplitude code -4096 = ...1 0000 0000 0000).  k_entropy codes it like any other item; it yields no bit.
-constexpr uint32_t kItPadValue = kItNop | kItDc | 0xF001u;
-// The EOB item (rle.c:121-123) in the same style: DC-flagged, size 13, amplitude bits all zero (value -8191); k_entropy's table
-// holds the EOB code under "DC size 13".  A non-DC item is therefore always a non-zero AC coefficient.
-constexpr uint32_t kItEobValue = kItDc | 0xE001u;
-constexpr int kTileItemCap = (kTileBlocks * 65 + 64 + 4 + 63) / 64 * 64;   // 2176 words
-constexpr int kTileRecord = kTileItemCap - 4;
-static_assert(kTileBlocks * 65 + 64 <= kTileRecord, "the per-tile record must lie behind the longest list and its read-ahead");
+// Per-tile symbol lists (private to k_tile_encode: built in LDS, coded by the wave that built them, never written out).
+// An item is one symbol-to-be, 4 bytes: bits 15..0 the value (int16), bits 24..19 the zigzag position (so that the upper
+// half is pos << 3: the producer adds the site's position with an inline constant, and the coder's run is one 16-bit
+// subtraction).  A block's run is: DC item, non-zero AC items, EOB item unless zigzag 63 is non-zero.  DC, EOB and padding
+// items have position 0 ("class D": coded from row 0 of the code table, whatever precedes them); a non-zero AC item always
+// has position >= 1.
+// The padding item: size 12 -- a size the table has no code for -- with all-zero amplitude bits (value -4095: amplitude code
+// -4096 = ...1 0000 0000 0000): it yields no bit.  It stands in for the DC of a tile's FIRST block, whose predictor is the last
+// block of the tile before (rle.c:59-70): that one symbol is coded by k_segment_merge, which knows both.
+constexpr uint32_t kItPadValue = 0xF001u;
+// The EOB item (rle.c:121-123) in the same style: size 13, amplitude bits all zero (value -8191); row 0 of the code table
+// holds the EOB code under "size 13".
+constexpr uint32_t kItEobValue = 0xE001u;
+constexpr int kStageItemCap = 8 * 132;          // items a wave's LDS region holds (the tile's dead luma stash): 1056 >= 16 blocks x 65
+
+// Code table of k_tile_encode (LDS), built once on the host (quant_consts.cpp: build_code_table), independent of the quality.
+// Entry (row r, fb) at word kCodeLead + 32 r + fb:
+//   r   0: class D (fb selects the DC size, 12 = no code, 13 = EOB); r >= 1: AC symbol with run r - 1 (runs >= 16: the entry
+//       is that of run & 15 and carries the number of ZRL symbols in front of it, rle.c:99-103)
+//   fb  v_ffbh_i32 of twice the amplitude code: 31 - size, or -1 for a zero value (size 0)
+//   entry: bits 31..16 the Huffman code LEFT-ALIGNED, 15..8 code length + size, 6..5 ZRLs, 4..0 code length
+constexpr int kCodeLead = 32;
+constexpr int kCodeRows = 64;
+constexpr int kCodeWords = kCodeLead + kCodeRows * 32;               // 2080
+constexpr uint32_t kZrlBits = 11, kZrlCode = 0x7F9u;                  // symbol 0xF0: '11111111001' (jpeg_tables.c:36-48)
+
+// Per-tile output of k_tile_encode in HBM: an 8-word record followed by the tile's bit string (MSB-first, from word 8):
+// every symbol of the tile except the DC of its first block.
+//   record: {bits of the string, DC of the first block (absolute), DC of the last block, exact-order fallbacks,
+//            symbols (run/size symbols incl. ZRLs and the first DC), 0, 0, 0}
+constexpr int kTileRecWords = 8;
+constexpr int kTileStrCap = ((kTileBlocks * kMaxBlockBits + 31) / 32 + 2 + kTileRecWords + 63) / 64 * 64;   // words reserved per tile (1792)
+constexpr int kTileHeadWords = 128;             // record + the first 120 string words leave the kernel as ONE 8-byte-per-lane store
 
 struct MfmaTables {
     uint32_t afrag[kAFragWords];   // kMfmaScale * LUT-product matrix as two integer-valued binary16 terms (lo 2^-11, hi), MFMA A-operand order
@@ -98,7 +115,8 @@ constexpr int kSegGroup = 4;
 
 struct TransformOutM {
     const MfmaTables *tables;   // device copy
-    uint32_t *tile_items;       // [num_tiles][kTileItemCap]
+    uint32_t *tile_str;         // [num_tiles][kTileStrCap]: record + bit string of every tile
+    const uint32_t *code_tab;   // [kCodeWords] device copy of the code table
     uint32_t *tile_ctr;         // [64 groups][32 words]: word 0 = ticket counter of the group's tile hand-out; zero at launch
     uint32_t *tile_ctr_next;    // the set the NEXT launch on this context uses: zeroed by this launch
     unsigned long long *stamps; // per-wave phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
@@ -110,15 +128,16 @@ struct TransformOutM {
 // kernel trace reports as its duration -- an event recorded in front of a launch also sees the dispatch latency.
 int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream, void *const *ev = nullptr);
 
-struct EntropyArgs {            // k_entropy: per-tile symbol lists -> per-segment bit strings
-    const uint32_t *tile_items;
+struct MergeArgs {              // k_segment_merge: the tile strings of a segment -> ONE bit string per segment + its numbers
+    const uint32_t *tile_str;
     const uint32_t *huff;           // [272] (len << 16) | code: AC by run/size symbol, then 16 DC sizes
     int32_t num_segs, segs_per_row, tiles_per_row;     // per image
     int32_t seg_begin, seg_end;     // segments this launch codes (whole images: 0, batch * num_segs)
     int32_t tiles_per_image;        // a batch: segment s belongs to image s / num_segs, whose tiles start at image * tiles_per_image
     SegArrays seg;
+    uint32_t *status;               // ScanStats::status: bit 1 = a tile record did not fit its reservation (JPEGAMD_ERR_RLE_CAPACITY)
 };
-int launch_entropy(const EntropyArgs &a, void *stream, void *const *ev = nullptr);
+int launch_segment_merge(const MergeArgs &a, void *stream, void *const *ev = nullptr);
 
 // Post-processing (jpegamd_finalize.hip): global bit / stuffing offsets, stitch, stuffing, container -- ONE launch.
 struct FinalizeArgs {
@@ -159,6 +178,7 @@ void quant_table_for_quality(int quality, uint8_t table[64]);
 // A-row order of the pipeline: lane half h, site s <-> zigzag 16(s>>3) + 8h + (s&7)
 void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64] /*by raster k, may be null*/);
 void build_huffman_words(uint32_t words[272]);
+void build_code_table(uint32_t words[kCodeWords]);
 void cos_lut_copy(float out[64]);              // COS_LUT[x][u] as the kernels use it (natural_c/src/core/dct.c:9-18)
 size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]);
 

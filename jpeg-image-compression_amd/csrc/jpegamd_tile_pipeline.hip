@@ -1,4 +1,4 @@
-// jpegamd_tile_pipeline.hip -- k_tile_transform: pixels -> per-tile symbol lists (first of the pipeline's three kernels).
+// jpegamd_tile_pipeline.hip -- k_tile_encode: pixels -> per-tile Huffman bit strings (first of the pipeline's three kernels).
 //
 // Persistent 512-thread workgroups; one wave-iteration per TILE of 32 blocks of one block row:
 //   luma (converter.c:31-51,60-90)            v_dot4 per pixel, straight into binary16 MFMA operands
@@ -7,16 +7,21 @@
 //   quantisation (quantization.c:34-36)       guard-band quantiser; a coefficient within delta of a rounding tie is recomputed in
 //                                             the reference's own float order (one coefficient per wave pass)
 //   zigzag (zigzag.c:21-68)                   the matrix rows are stored in grouped zigzag order: no data movement
-//   RLE front half (rle.c:51-127)             DC DPCM inside the tile, non-zero compaction: every lane appends its block's
+//   RLE (rle.c:51-127)                        DC DPCM inside the tile, non-zero compaction: every lane appends its block's
 //                                             symbols-to-be -- (zigzag position, value) items: DC, non-zero ACs, EOB -- to the
-//                                             tile's list, built in LDS and written out as four 16-byte-per-lane stores
-// k_entropy (jpegamd_entropy.hip) turns the lists of a segment's 8 tiles into one Huffman bit string, k_finalize
-// (jpegamd_finalize.hip) stitches the segments.  Tiles are handed out dynamically through 64 ticket counters; the next tile's
-// pixel rows are requested as soon as its ticket is in.  A launch covers one image, a block-row shard of one, or a batch of
-// images of one geometry (ImageDesc::batch).  DESIGN.md 4.0-4.1 has the measurements behind each choice.
-//
-// Extra HBM traffic: 4 bytes per symbol written and read once (~23 MB per 8192^2 photo-like image, vs 201 MB of pixels).
-// Lists are reserved at the worst case (65 items per block) so any content fits.
+//                                             tile's list in LDS
+//   Huffman coding (huffman.c:121-193)        the SAME wave codes its list, two items per lane: size / amplitude / run from the
+//                                             item and its predecessor, ONE table lookup per symbol, a wave prefix sum over the
+//                                             bit counts, ds_or into a bit window in LDS -- the tile's bit string, which leaves the
+//                                             kernel with its 8-word record as ONE 8-byte-per-lane store
+// k_segment_merge (jpegamd_entropy.hip) joins the strings of a segment's 8 tiles (and codes the one symbol per tile that
+// needs the tile before: the DC of its first block), k_finalize (jpegamd_finalize.hip) stitches the segments.  Round 2 wrote the
+// item lists to HBM (24 MB per 8192^2 picture) and coded them in a second kernel that read them back (28 MB): 1.31 x the
+// algorithmic traffic, a launch whose waves all start cold, and two phases that could not overlap -- this kernel's waves spent
+// 48 % of their time in s_waitcnt while that one's were bound by VALU issue.
+// Tiles are handed out dynamically through 64 ticket counters; the next tile's pixel rows are requested as soon as its ticket
+// is in, and are in flight during the appends and the coding.  A launch covers one image, a block-row shard of one, or a batch
+// of images of one geometry (ImageDesc::batch).  DESIGN.md 4.0-4.1 has the measurements behind each choice.
 #include <hip/hip_ext.h>
 #include "jpegamd_device.h"
 
@@ -119,12 +124,11 @@ constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket count
 #ifndef JPEGAMD_TILE_WAVES
 #define JPEGAMD_TILE_WAVES 4
 #endif
-#ifndef JPEGAMD_COPY_STORES
-#define JPEGAMD_COPY_STORES 4
-#endif
-constexpr int kCopyStores = JPEGAMD_COPY_STORES;                 // 16-byte-per-lane stores that close every iteration
-constexpr int kStageItems = kCopyStores * 256 - 1;               // longest list built in LDS (+ its padding item)
-static_assert(kCopyStores * 256 <= 8 * 132, "the staged list lives in the tile's luma buffer");
+constexpr int kWinWords = 256;                                   // bit window per wave in LDS: the tile's record (8 words) + 248 string words
+constexpr int kWinStr = kWinWords - kTileRecWords;
+constexpr int kPassItems = 128;                                  // items coded per pass: two per lane
+static_assert(16 * 65 <= kStageItemCap, "half a tile's items (16 blocks) always fit the staging region");
+static_assert(kPassItems * (27 + 3 * (int)kZrlBits) / 32 + 4 <= kWinStr, "the window takes a whole pass, ZRLs included");
 
 struct TileSched {            // division-free launch geometry, filled by launch_tile_transform
     int32_t grp_shift;        // workgroups form 1 << grp_shift ticket groups (blockIdx & mask)
@@ -133,12 +137,13 @@ struct TileSched {            // division-free launch geometry, filled by launch
 };
 
 // Appends of one group's sites to the staged list, branch-free: per site one compare that narrows EXEC to the lanes holding
-// a non-zero value, the SDWA add that writes the zigzag position into the value's upper half, the LDS write, the address
-// increment (5 issue slots; the compiler's version costs 4 slots for a site no lane uses and ~10, with a taken branch, for
-// the others).  `addr` is the byte address in LDS of the lane's next item; values are modified in place.
+// a non-zero value, the SDWA add that writes 8 x the zigzag position into the value's upper half (the item format of
+// jpegamd_internal.h; 8 J is an inline constant for every J), the LDS write, the address increment (5 issue slots; the
+// compiler's version costs 4 slots for a site no lane uses and ~10, with a taken branch, for the others).  `addr` is the
+// byte address in LDS of the lane's next item, `zg` 8 x the zigzag position of the group's site 0; values are modified in place.
 #define JPEGAMD_APPEND_SITE(V, J)                                                                                       \
     "v_cmpx_ne_u32_e32 0, %[" #V "]\n\t"                                                                                \
-    "v_add_u32_sdwa %[" #V "], %[zg], " #J " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
+    "v_add_u32_sdwa %[" #V "], %[zg], 8*" #J " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
     "ds_write_b32 %[addr], %[" #V "]\n\t"                                                                               \
     "v_add_u32_e32 %[addr], 4, %[addr]\n\t"                                                                            \
     "s_mov_b64 exec, %[save]\n\t"
@@ -165,9 +170,37 @@ __device__ __forceinline__ void append_group_lds(uint32_t &addr, int (&v)[8], ui
 }
 #undef JPEGAMD_APPEND_SITE
 
+// ---- the coder ---------------------------------------------------------------------------------------------------------
+// item -> code table entry + left-aligned bit string (Huffman code, then amplitude bits: huffman.c:145-153,176-186).
+// `prev` is the item in front of it in the list; only its position field is used, and only by a non-zero AC item, whose
+// predecessor is always an item of the same block (its DC item, position 0, or the non-zero coefficient before it).
+//   amplitude code  w = v + (v >> 31)                     rle.c:24-35: v, or v - 1 when negative
+//   size            31 - v_ffbh_i32(2 w), -1 -> 0         rle.c:9-22 without the abs / zero special cases
+//   row             8 x gap to the predecessor = 8 x (run + 1); class D items (position 0) take row 0 whatever precedes them:
+//                   min(gap, own position) -- a gap is never larger than the position, and a class D item's is 0
+__device__ __forceinline__ void code_item(uint32_t it, uint32_t prev, const uint32_t *tab /*LDS: the code table*/, uint32_t &e, uint32_t &bits) {
+    const int v = (int)(short)(it & 0xFFFFu);
+    const int x2 = (v + (v >> 31)) << 1;
+    int fb;
+    asm("v_ffbh_i32 %0, %1" : "=v"(fb) : "v"(x2));
+    const uint32_t al = (uint32_t)x2 << (fb & 31);                            // amplitude bits, left-aligned
+    const uint32_t pos8 = it >> 16;
+    const uint32_t row8 = min(pos8 - (prev >> 16), pos8);
+    e = tab[kCodeLead + (int)(row8 << 2) + fb];
+    bits = (e & 0xFFFF0000u) | (al >> (e & 31u));
+}
+
+// OR a left-aligned string (hi:lo, <= 64 bits) into the window at bit `rel`.
+__device__ __forceinline__ void window_or(uint32_t *win, uint32_t rel, uint32_t hi, uint32_t lo, bool third) {
+    const uint32_t w = rel >> 5, sh = rel & 31u;
+    atomicOr(&win[w], __builtin_amdgcn_alignbit(0u, hi, sh));
+    atomicOr(&win[w + 1], __builtin_amdgcn_alignbit(hi, lo, sh));
+    if (third) atomicOr(&win[w + 2], __builtin_amdgcn_alignbit(lo, 0u, sh));
+}
+
 template <bool kTaps>
 __global__ __launch_bounds__(64 * kWavesT) __attribute__((amdgpu_waves_per_eu(JPEGAMD_TILE_WAVES, JPEGAMD_TILE_WAVES)))
-void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSched sch) {
+void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched sch) {
     __shared__ __attribute__((aligned(16))) uint32_t s_afrag[kAFragWords];
     __shared__ float2 s_q[64];                 // (multiplier, threshold) by zigzag position
     __shared__ float s_qstep[64];
@@ -180,7 +213,10 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
     // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
     // prefetched rows of the NEXT tile as well: ~40 % of a tile's time per event (tools/stamp_profile_tile.py).
-    __shared__ __attribute__((aligned(16))) uint32_t s_pix[kWavesT][8 * 132];
+    // After the exact-order phase the same words hold the tile's item list.
+    __shared__ __attribute__((aligned(16))) uint32_t s_pix[kWavesT][kStageItemCap];
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[kWavesT][kWinWords];      // per wave: the tile's record + bit window; all zero between tiles
+    __shared__ __attribute__((aligned(16))) uint32_t s_code[kCodeWords];
 #ifdef JPEGAMD_STAMPS
     unsigned long long st_rt0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
@@ -191,6 +227,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const uint4 *src = reinterpret_cast<const uint4 *>(out.tables->afrag);
         uint4 *dst = reinterpret_cast<uint4 *>(s_afrag);
         for (int i = t; i < kAFragWords / 4; i += 64 * kWavesT) dst[i] = src[i];
+        const uint4 *csrc = reinterpret_cast<const uint4 *>(out.code_tab);
+        for (int i = t; i < kCodeWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(s_code)[i] = csrc[i];
+        for (int i = t; i < kWavesT * kWinWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(&s_win[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
         if (t < 64) {
             s_q[t] = make_float2(out.tables->qmul[t], out.tables->qthr[t]);
             s_qstep[t] = out.tables->qstep[t];
@@ -294,7 +333,7 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
     TileGeo tg = geo(tile);
     if (first < cur_hi && tg.interior) request_rows(tg, raw);
 #ifdef JPEGAMD_STAMPS
-    unsigned long long st_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
+    unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_last)::"memory");
     const unsigned long long st_c1 = st_last;
 #endif
@@ -503,22 +542,23 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
         const uint32_t starts = (pre << 8) + (h ? partner : 0u);                    // byte G: items of the block ahead of my run G
         const uint32_t blk_base = incl - tb;
 
-        // DC prediction inside the tile (rle.c:59-70); the first block keeps its absolute value, the entropy
-        // kernel subtracts the previous tile's last DC.
+        // DC prediction inside the tile (rle.c:59-70).  The DC of the tile's FIRST block needs the last block of the tile before:
+        // a padding item holds its place in the list, k_segment_merge codes the symbol from the two tiles' records.
         const int pred = lane_shift_up1(n[0]);
-        const uint32_t dc_item = (b == 0) ? (kItDc | kItFirst | (uint32_t)(n[0] & 0xFFFF)) : (kItDc | (uint32_t)((n[0] - pred) & 0xFFFF));
+        const uint32_t dc_item = (b == 0) ? kItPadValue : (uint32_t)((n[0] - pred) & 0xFFFF);
+        const int first_dc = __builtin_amdgcn_readlane(n[0], 0), last_dc = __builtin_amdgcn_readlane(n[0], nblk - 1);
         TSTAMP(6);   // counts + scans
 
-        // The ticket requested at the top of the iteration is collected here, BEFORE the item stores are issued:
-        // the wait for it then covers no younger memory operation (built with the atomic optimizer off -- its
-        // expansion reads the result back, and waits for vmcnt(0), right behind the atomic).
+        // The ticket requested behind the MFMAs is collected here, BEFORE any younger memory operation is issued
+        // (built with the atomic optimizer off -- its expansion reads the result back, and waits for vmcnt(0), right
+        // behind the atomic).
         int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
         TileGeo tg_next = tg;
         int tile_next = tile;
         if (nxt < cur_hi) { tile_next = to_tile(nxt); tg_next = geo(tile_next); }
-        // The next tile's pixel rows: 8 loads, in flight behind the appends.  vmcnt retires in issue order, so the wait at
-        // the top of the loop must not have to count a VARYING number of younger stores: whatever path the appends take,
-        // exactly kCopyStores stores close the iteration (the compiler then waits for vmcnt(kCopyStores), not 0).
+        // The next tile's pixel rows: 8 loads, in flight behind the appends and the coding.  vmcnt retires in issue order, so
+        // the wait at the top of the loop must not have to count a VARYING number of younger stores: whatever path the tile
+        // takes, exactly ONE store closes the iteration (the compiler then waits for vmcnt(1), not 0).
         if (nxt < cur_hi && tg_next.interior) {
             request_rows(tg_next, raw);
         } else {                               // (defined on every path -- by an empty asm, i.e. no instruction: else the old rows stay
@@ -527,28 +567,34 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
 #pragma unroll
                 for (int i = 0; i < 6; ++i) asm volatile("" : "=v"(raw[s].d[i]));
         }
-        // ---- 6. append the items (from word 0 of the tile's list) ----
-        // Per item: one SDWA add writes the zigzag position into the upper half of the value's own register, one write, one
-        // offset increment.  Up to kStageItems items the list is built in LDS (the tile's luma there is dead by now) and leaves
-        // as whole 16-byte pieces per lane: 4-byte stores scattered over the list's lines cost one L2 request per lane-run and
-        // line (6.5 M requests per 8192^2 image, tools/ubench/launch_cost.hip: 30 us of L2 time on their own).
-        uint32_t *list = out.tile_items + (size_t)tile * kTileItemCap;
-        const bool staged = t_all <= (uint32_t)kStageItems;
-        uint32_t *stage = &s_pix[wave][0];
-        if (staged) {
-            if (active) {
-                const uint32_t stage_addr = (uint32_t)(uintptr_t)stage;      // LDS byte address (the low 32 bits of the flat one)
+        TSTAMP(7);   // ticket, geometry of the next tile, row requests
+
+        // ---- 6. the tile's item list, in LDS (the tile's luma there is dead by now) ----
+        // Per item: one SDWA add writes 8 x the zigzag position into the upper half of the value's own register, one LDS
+        // write, one address increment.  A list longer than the staging region (noise, very high qualities: up to 65 items
+        // per block) is built and coded in two halves of 16 blocks each; the values are modified in place, each lane's in
+        // the half its block belongs to.
+        uint32_t *const str = out.tile_str + (size_t)tile * kTileStrCap;
+        uint32_t *const stage = &s_pix[wave][0];
+        uint32_t *const win = &s_win[wave][0];
+        const int nhalves = t_all <= (uint32_t)kStageItemCap ? 1 : 2;
+        const uint32_t items_h0 = nhalves == 2 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 15) : t_all;
+        uint32_t cur_bits = 0, wbase = 0, nzrl = 0;          // bits of the tile's string so far; string words already in HBM; ZRL symbols
+        uint32_t carry_item = 0;                             // the last item of the pass before
+#pragma unroll 1
+        for (int half = 0; half < nhalves; ++half) {
+            const uint32_t list_base = half ? items_h0 : 0u;
+            const uint32_t nitems = half ? t_all - items_h0 : items_h0;
+            if (active && (nhalves == 1 || (b >> 4) == half)) {
+                const uint32_t stage_addr = (uint32_t)(uintptr_t)stage - list_base * 4u;      // LDS byte address (the low 32 bits of the flat one)
                 uint32_t addr = 0;
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     if (!gact[G]) continue;
                     addr = stage_addr + (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
-                    const uint32_t zg = (uint32_t)(16 * G + 8 * h);
-                    int vv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vv[j] = n[8 * G + j];
+                    const uint32_t zg = (uint32_t)(8 * (16 * G + 8 * h));
                     if (G == 0) {
-                        // site 0: the DC item (always stored, its flags live in the upper half) in lanes h == 0, zigzag 8 in lanes h == 1
+                        // site 0: the DC item (always stored) in lanes h == 0, zigzag 8 in lanes h == 1
                         uint32_t first_item = dc_item;
                         if (h) {
                             first_item = (uint32_t)n[0];
@@ -559,9 +605,9 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                             asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(first_item) : "memory");
                             addr += 4u;
                         }
-                        append_group_lds<true>(addr, vv, zg);
+                        append_group_lds<true>(addr, reinterpret_cast<int (&)[8]>(n[0]), zg);
                     } else {
-                        append_group_lds<false>(addr, vv, zg);
+                        append_group_lds<false>(addr, reinterpret_cast<int (&)[8]>(n[8 * G]), zg);
                     }
                 }
                 if (eob) {
@@ -570,64 +616,109 @@ void k_tile_transform(const ImageDesc im, const TransformOutM out, const TileSch
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the asm writes are invisible to the compiler's counters
-            if (lane == 0 && (t_all & 1u)) stage[t_all] = kItPadValue;  // k_entropy's lanes take two items each: even count per list
-        } else {
-            const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, kTileRecord * 4, 0x00020000);
-            if (active) {
-                uint32_t off = 0;
+            TSTAMP(8);   // appends
+
+            // ---- 7. Huffman coding of the list (rle.c:83-123, huffman.c:145-188): two items per lane and pass ----
+#pragma unroll 1
+            for (uint32_t base = 0; base < nitems; base += (uint32_t)kPassItems) {
+                const uint32_t rem = nitems - base;
+                const uint2 pair = *reinterpret_cast<const uint2 *>(&stage[base + 2u * (uint32_t)lane]);
+                uint32_t ia = pair.x, ib = pair.y;
+                if (rem < (uint32_t)kPassItems) {                 // the list's last pass: the lanes beyond it code padding items (no bits)
+                    ia = 2u * (uint32_t)lane < rem ? ia : kItPadValue;
+                    ib = 2u * (uint32_t)lane + 1u < rem ? ib : kItPadValue;
+                }
+                // the item in front of a lane's first item: the second item of the lane before (lane 0: the pass before)
+                const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_item, (int)ib, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+                carry_item = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+                uint32_t ea, eb, sa, sb;
+                code_item(ia, pa, s_code, ea, sa);
+                code_item(ib, ia, s_code, eb, sb);
+                uint32_t la = (ea >> 8) & 0xFFu, lb = (eb >> 8) & 0xFFu;
+                const bool any_zrl = __ballot(((ea | eb) & 0x60u) != 0u) != 0ull;
+                if (__builtin_expect(any_zrl, 0)) {               // runs >= 16 (rle.c:99-103): ZRL symbols in front, coded below
+                    const uint32_t za = (ea >> 5) & 3u, zb = (eb >> 5) & 3u;
+                    la += za * kZrlBits;
+                    lb += zb * kZrlBits;
+                    nzrl += (uint32_t)wave_sum_i32((int)(za + zb));
+                }
+                const uint32_t lab = la + lb;
+                const uint32_t incl_b = wave_incl_scan_u32(lab);
+                const uint32_t pass_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl_b, 63);
+                // The window is written out in the middle of a tile only when the next pass might not fit (very dense tiles).
+                if (__builtin_expect(((cur_bits + pass_bits) >> 5) - wbase + 3u > (uint32_t)kWinStr, 0)) {
+                    const uint32_t done = (cur_bits >> 5) - wbase;              // complete words in the window
+                    if (done) {
+                        const uint32_t part = win[kTileRecWords + done];
+                        for (uint32_t j = (uint32_t)lane; j < done; j += 64) str[kTileRecWords + wbase + j] = win[kTileRecWords + j];
 #pragma unroll
-                for (int G = 0; G < 4; ++G) {
-                    if (!gact[G]) continue;
-                    off = (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
-                    const uint32_t zg = (uint32_t)(16 * G + 8 * h);
-                    if (G == 0 && h == 0) { __builtin_amdgcn_raw_buffer_store_b32(dc_item, lrsrc, off, 0, 0); off += 4u; }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int v = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];
-                        if (v != 0) {
-                            uint32_t item = (uint32_t)v;
-                            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
-                                : "+v"(item) : "v"(zg), "n"(j));
-                            __builtin_amdgcn_raw_buffer_store_b32(item, lrsrc, off, 0, 0);
-                            off += 4u;
-                        }
+                        for (int i = 0; i < kWinWords / 64; ++i) win[i * 64 + lane] = 0u;
+                        if (lane == 0) win[kTileRecWords] = part;
+                        wbase += done;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // leave no store of a varying count pending
                     }
                 }
-                if (eob) {
-                    if (!gact[3]) off = (blk_base + (starts >> 24)) * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b32(kItEobValue, lrsrc, off, 0, 0);
+                const uint32_t rel = (uint32_t)(kTileRecWords * 32) + cur_bits + incl_b - lab - wbase * 32u;
+                if (__builtin_expect(!any_zrl, 1)) {
+                    // join the lane's two strings: (bits_a : bits_b >> len_a), <= 54 bits
+                    const uint32_t hi = sa | __builtin_amdgcn_alignbit(0u, sb, la);
+                    const uint32_t lo = __builtin_amdgcn_alignbit(sb, 0u, la);
+                    window_or(win, rel, hi, lo, __ballot((rel & 31u) + lab > 64u) != 0ull);
+                } else {
+                    // symbol by symbol, each with its ZRLs in front (huffman.c:158-188 codes them as ordinary symbols)
+                    const auto with_zrl = [&](uint32_t bits, uint32_t z, uint32_t &hi, uint32_t &lo) {
+                        unsigned long long a64 = (unsigned long long)bits << 32;
+                        for (uint32_t q = 0; q < 3; ++q)
+                            if (q < z) a64 = (a64 >> kZrlBits) | ((unsigned long long)(kZrlCode << (32u - kZrlBits)) << 32);
+                        hi = (uint32_t)(a64 >> 32);
+                        lo = (uint32_t)a64;
+                    };
+                    uint32_t hi, lo;
+                    with_zrl(sa, (ea >> 5) & 3u, hi, lo);
+                    window_or(win, rel, hi, lo, true);
+                    with_zrl(sb, (eb >> 5) & 3u, hi, lo);
+                    window_or(win, rel + la, hi, lo, true);
                 }
+                cur_bits += pass_bits;
             }
-            if (lane == 0 && (t_all & 1u)) list[t_all] = kItPadValue;
+            TSTAMP(9);   // coding
         }
-        if (lane == 0)
-            *reinterpret_cast<uint4 *>(list + kTileRecord) =
-                make_uint4(t_all, (uint32_t)__builtin_amdgcn_readlane(n[0], nblk - 1), (uint32_t)nexact, 0u);
-        {   // the closing stores: 16 bytes per lane and store out of the staged list; lanes beyond it (all of them on the
-            // direct path) fall to the descriptor's range check.  Whole 16-byte pieces: the list's capacity is a multiple of 16.
-            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-            const uint32_t staged_bytes = staged ? ((t_all + 3u) & ~3u) * 4u : 0u;
-            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(list, 0, staged_bytes, 0x00020000);
-#pragma unroll
-            for (int i = 0; i < kCopyStores; ++i) {
-                const u32x4 piece = *reinterpret_cast<const u32x4 *>(&stage[i * 256 + lane * 4]);
-                __builtin_amdgcn_raw_buffer_store_b128(piece, crsrc, (uint32_t)(i * 1024 + lane * 16), 0, 0);
+
+        // ---- 8. record + string leave the kernel ----
+        {
+            const uint32_t nw = ((cur_bits + 31u) >> 5) - wbase;                // string words still in the window
+            const bool whole = wbase == 0u && nw <= (uint32_t)(kTileHeadWords - kTileRecWords);
+            if (__builtin_expect(!whole, 0)) {                                  // a long string: its last words go out one by one
+                for (uint32_t j = (uint32_t)lane; j < nw; j += 64) str[kTileRecWords + wbase + j] = win[kTileRecWords + j];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (lane == 0) {
+                *reinterpret_cast<uint4 *>(win) = make_uint4(cur_bits, (uint32_t)first_dc, (uint32_t)last_dc, (uint32_t)nexact);
+                *reinterpret_cast<uint4 *>(win + 4) = make_uint4(t_all + nzrl, 0u, 0u, 0u);
+            }
+            // the closing store: record + the first 120 string words, 8 bytes per lane; lanes beyond the string fall to the
+            // descriptor's range check (whole 8-byte pieces: the window is zero behind the string)
+            typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+            const uint32_t head_bytes = whole ? (((uint32_t)kTileRecWords + nw + 1u) & ~1u) * 4u : (uint32_t)kTileRecWords * 4u;
+            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(str, 0, head_bytes, 0x00020000);
+            const u32x2 piece = *reinterpret_cast<const u32x2 *>(&win[lane * 2]);
+            __builtin_amdgcn_raw_buffer_store_b64(piece, crsrc, (uint32_t)(lane * 8), 0, 0);
+            *reinterpret_cast<uint4 *>(&win[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);       // the window is all zero again
         }
 #undef JPEGAMD_ACC
-        TSTAMP(7);   // appends
+        TSTAMP(10);  // record, copy-out
         li = nxt;
         tile = tile_next;
         tg = tg_next;
     }
 #ifdef JPEGAMD_STAMPS
-    {   // [8] kernel entry, [9] loop start, [10] loop end in 100 MHz ticks; [11] shader cycles of the loop
+    {   // [0..10] phase sums; [11] kernel entry, [12] loop start, [13] loop end in 100 MHz ticks; [14] shader cycles of the loop
         unsigned long long st_rt2, st_c2;
         asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt2), "=s"(st_c2)::"memory");
         if (lane == 0 && out.stamps) {
             unsigned long long *o = out.stamps + (size_t)(blockIdx.x * kWavesT + wave) * 16;
-            for (int i = 0; i < 8; ++i) o[i] = st_sum[i];
-            o[8] = st_rt0; o[9] = st_rt1; o[10] = st_rt2; o[11] = st_c2 - st_c1;
+            for (int i = 0; i < 11; ++i) o[i] = st_sum[i];
+            o[11] = st_rt0; o[12] = st_rt1; o[13] = st_rt2; o[14] = st_c2 - st_c1;
         }
     }
 #endif
@@ -647,9 +738,9 @@ int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool ta
     const uint64_t magic = 0x100000000ull / (uint64_t)im.tiles_per_row + 1ull;
     sch.tpr_magic = magic > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)magic;   // tiles_per_row == 1: the correction step makes up for it
     const dim3 grid(wgs), block(64 * kWavesT);
-    if (taps) hipLaunchKernelGGL(k_tile_transform<true>, grid, block, 0, (hipStream_t)stream, im, out, sch);
-    else if (ev) hipExtLaunchKernelGGL(k_tile_transform<false>, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, im, out, sch);
-    else hipLaunchKernelGGL(k_tile_transform<false>, grid, block, 0, (hipStream_t)stream, im, out, sch);
+    if (taps) hipLaunchKernelGGL(k_tile_encode<true>, grid, block, 0, (hipStream_t)stream, im, out, sch);
+    else if (ev) hipExtLaunchKernelGGL(k_tile_encode<false>, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, im, out, sch);
+    else hipLaunchKernelGGL(k_tile_encode<false>, grid, block, 0, (hipStream_t)stream, im, out, sch);
     return (int)hipGetLastError();
 }
 

@@ -94,6 +94,33 @@ void build_huffman_words(uint32_t words[272]) {
     fill(kDcCounts, kDcSymbols, words + 256);
 }
 
+void build_code_table(uint32_t words[kCodeWords]) {
+    // The coder's view of the same codes (jpegamd_internal.h: entry (row, fb)).  rle.c:9-35 (size, amplitude), rle.c:99-123
+    // (ZRL, run/size symbol, EOB), huffman.c:145-188 (code, then amplitude bits).
+    uint32_t hw[272];
+    build_huffman_words(hw);
+    std::memset(words, 0, kCodeWords * sizeof(uint32_t));
+    auto entry = [](uint32_t w, uint32_t size, uint32_t zrl) -> uint32_t {
+        const uint32_t clen = w >> 16, code = w & 0xFFFFu;
+        // a symbol the tables have no code for gets no code bits, but its amplitude bits are still written (huffman.c:36,176-186)
+        return ((clen ? code << (16u - clen) : 0u) << 16) | ((clen + size) << 8) | (zrl << 5) | clen;
+    };
+    for (int r = 0; r < kCodeRows; ++r)
+        for (int fb = -1; fb <= 30; ++fb) {
+            if (fb >= 0 && fb < 18) continue;                       // sizes above 13 do not occur
+            const uint32_t size = fb < 0 ? 0u : (uint32_t)(31 - fb);
+            uint32_t e = 0;
+            if (r == 0) {
+                if (size <= 11) e = entry(hw[256 + size], size, 0);
+                else if (size == 13) e = entry(hw[0x00], 0, 0);    // EOB: the code alone
+            } else if (size >= 1 && size <= 11) {                   // a non-zero AC coefficient
+                const uint32_t run = (uint32_t)(r - 1);
+                e = entry(hw[((run & 15u) << 4) | size], size, run >> 4);
+            }
+            words[kCodeLead + 32 * r + fb] = e;
+        }
+}
+
 size_t build_jfif_prefix(int width, int height, const uint8_t table[64], uint8_t out[328]) {
     // natural_c/src/io/jpeg_handler.c:7-110 (byte layout of the six marker segments).
     uint8_t *p = out;
