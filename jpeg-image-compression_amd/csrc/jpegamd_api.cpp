@@ -39,7 +39,7 @@ struct JpegAmdEncoder {
     ScanStats mirror;            // host copy of stats_dev, fetched by finish()
     MfmaTables *tables_dev = nullptr;
     MfmaTables *tables_host = nullptr;          // this context's own staging copy (contexts may be driven from different threads)
-    uint32_t *tile_str = nullptr, *tile_ctr = nullptr, *code_tab = nullptr;
+    uint32_t *tile_head = nullptr, *tile_over = nullptr, *tile_ctr = nullptr, *code_tab = nullptr;
     int ctr_set = 0;                    // which half of tile_ctr the next k_tile_transform launch uses
     unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
     // cached constants
@@ -163,7 +163,8 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY_CREATE(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));
     HIP_TRY_CREATE(hipMemset(e->stats_dev, 0, sizeof(ScanStats)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->tables_dev, sizeof(MfmaTables)));
-    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_str, (size_t)e->max_tiles * kTileStrCap * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_head, ((size_t)e->max_tiles + 1) * kTileHeadWords * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->tile_over, (size_t)e->max_tiles * kTileOverCap * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->code_tab, kCodeWords * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->tile_ctr, 2 * 64 * 128));      // two sets of ticket-group cache lines, used alternately
     HIP_TRY_CREATE(hipMemset(e->tile_ctr, 0, 2 * 64 * 128));
@@ -189,7 +190,7 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (e->pending) hipStreamSynchronize(e->last_stream);
     hipFree(e->seg.words); hipFree(e->seg.bits); hipFree(e->seg.syms); hipFree(e->seg.exact); hipFree(e->seg.edge); hipFree(e->seg.ffin); hipFree(e->seg.grp_bits); hipFree(e->seg.grp_ff);
     hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev);
-    hipFree(e->tile_str); hipFree(e->code_tab); hipFree(e->tile_ctr); hipFree(e->stamps_dev);
+    hipFree(e->tile_head); hipFree(e->tile_over); hipFree(e->code_tab); hipFree(e->tile_ctr); hipFree(e->stamps_dev);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e->tables_host;
     delete e;
@@ -285,7 +286,7 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     std::memset(&to, 0, sizeof(to));
     to.tables = e->tables_dev; to.stamps = e->stamps_dev;
     to.tap_y = ty; to.tap_zz = tzz; to.tap_mask = tmask;
-    to.tile_str = e->tile_str; to.code_tab = e->code_tab;
+    to.tile_head = e->tile_head; to.tile_over = e->tile_over; to.code_tab = e->code_tab;
     // Launches on one context are stream-ordered by contract (they share the scratch): launch i draws tickets from set
     // i % 2 and zeroes the other one for launch i + 1.
     to.tile_ctr = e->tile_ctr + (e->ctr_set ? 64 * 32 : 0);
@@ -294,7 +295,7 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     if (im.tile_end > im.tile_begin) e->ctr_set ^= 1;      // (an empty range launches nothing)
     MergeArgs ea;
     std::memset(&ea, 0, sizeof(ea));
-    ea.tile_str = e->tile_str;
+    ea.tile_head = e->tile_head; ea.tile_over = e->tile_over;
     ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
     ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
     ea.tiles_per_image = im.batch > 1 ? im.num_tiles : 0;

@@ -54,22 +54,26 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
 
     // Every load whose address does not depend on data goes out first: the tiles' records, the record of the tile in front
     // of the segment (its last DC), and the first piece of every tile's string.
-    const uint32_t *tbase = a.tile_str + (size_t)tile0 * kTileStrCap;
-    const uint32_t *trec = tbase + (size_t)lane * kTileStrCap;           // lane t: tile t
+    const uint32_t *tbase = a.tile_head + (size_t)tile0 * kTileHeadWords;
+    const uint32_t *trec = tbase + (size_t)lane * kTileHeadWords;        // lane t: tile t
     uint4 rec = make_uint4(0u, 0u, 0u, 0u);
     uint32_t rsyms = 0, prev_last = 0;
     if (lane < ntiles) {
         rec = *reinterpret_cast<const uint4 *>(trec);                  // {string bits, first DC, last DC, exact-order fallbacks}
         rsyms = trec[4];
-        if (lane == 0 && tile_in_image > 0) prev_last = *(trec + 2 - kTileStrCap);   // the tile before (of the same image): its last DC
+        if (lane == 0 && tile_in_image > 0) prev_last = *(trec + 2 - kTileHeadWords);   // the tile before (of the same image): its last DC
     }
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
     u32x2 piece[kSegTiles];
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint32_t *>(tbase), 0, ntiles * kTileStrCap * 4, 0x00020000);
+    // (lanes 60..63 of a head piece, and tiles beyond the segment, fall to the range checks: zeros)
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(tbase), 0, ntiles * kTileHeadWords * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(a.tile_over + (size_t)tile0 * kTileOverCap), 0, ntiles * kTileOverCap * 4, 0x00020000);
 #pragma unroll
-    for (int t = 0; t < kSegTiles; ++t)                                  // tiles beyond the segment fall to the range check: zeros
-        piece[t] = __builtin_amdgcn_raw_buffer_load_b64(srsrc, (int)((uint32_t)lane * 8u), (int)((t * kTileStrCap + kTileRecWords) * 4), 0);
+    for (int t = 0; t < kSegTiles; ++t)
+        piece[t] = __builtin_amdgcn_raw_buffer_load_b64(      // (everything in the vector offset: the range check does not see the scalar one)
+            hrsrc, lane < kTileHeadStr / 2 ? (int)((uint32_t)lane * 8u) + (t * kTileHeadWords + kTileRecWords) * 4 : 0x7FFFFFF0, 0, 0);
 
 #pragma unroll
     for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
@@ -162,14 +166,14 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
         }
         const uint32_t nwords = (sb + 31u) >> 5;
         u32x2 pc = piece[t];
-        for (uint32_t w0 = 0; w0 < nwords; w0 += (uint32_t)kPieceWords) {
+        for (uint32_t w0 = 0; w0 < nwords; w0 += w0 ? (uint32_t)kPieceWords : (uint32_t)kTileHeadStr) {
             const uint32_t start = off + dl + w0 * 32u;                              // bit offset of the piece in the segment
-            if (w0) {                                                                // (only strings beyond 128 words come here)
+            if (w0) {                                                                // (only strings beyond the tile's head come here)
                 make_room(start, start + min(sb - w0 * 32u, (uint32_t)(kPieceWords * 32)));
-                pc = __builtin_amdgcn_raw_buffer_load_b64(srsrc, (int)((uint32_t)lane * 8u), (int)((t * kTileStrCap + kTileRecWords + (int)w0) * 4), 0);
+                pc = __builtin_amdgcn_raw_buffer_load_b64(orsrc, (int)((uint32_t)lane * 8u) + (t * kTileOverCap + (int)w0 - kTileHeadStr) * 4, 0, 0);
             }
-            // (a piece's words beyond the string are not all zero when the tile wrote its string word by word: mask by count)
-            const uint32_t left = nwords - w0;
+            // (a piece's words beyond the string are not zero: mask by count)
+            const uint32_t left = min(nwords - w0, w0 ? (uint32_t)kPieceWords : (uint32_t)kTileHeadStr);
             const uint32_t x0 = 2u * (uint32_t)lane < left ? pc[0] : 0u, x1 = 2u * (uint32_t)lane + 1u < left ? pc[1] : 0u;
             const uint32_t rel = start - wbase * 32u, wi = (rel >> 5) + 2u * (uint32_t)lane, sh = rel & 31u;
             if (2u * (uint32_t)lane < left) {

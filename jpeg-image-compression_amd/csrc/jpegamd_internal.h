@@ -27,9 +27,8 @@ constexpr int kAFragWords = 2 * 2 * 4 * 64 * 4;                      // [term][c
 constexpr float kMfmaScale = 2048.0f;                                // the accumulator chains hold kMfmaScale * LUT sum (hi chain + lo chain)
 
 // Per-tile symbol lists (private to k_tile_encode: built in LDS, coded by the wave that built them, never written out).
-// An item is one symbol-to-be, 4 bytes: bits 15..0 the value (int16), bits 24..19 the zigzag position (so that the upper
-// half is pos << 3: the producer adds the site's position with an inline constant, and the coder's run is one 16-bit
-// subtraction).  A block's run is: DC item, non-zero AC items, EOB item unless zigzag 63 is non-zero.  DC, EOB and padding
+// An item is one symbol-to-be, 4 bytes: bits 15..0 the value (int16), bits 21..16 the zigzag position (the producer writes
+// the upper half with one SDWA add of an inline constant, and the coder's run is one 16-bit subtraction).  A block's run is: DC item, non-zero AC items, EOB item unless zigzag 63 is non-zero.  DC, EOB and padding
 // items have position 0 ("class D": coded from row 0 of the code table, whatever precedes them); a non-zero AC item always
 // has position >= 1.
 // The padding item: size 12 -- a size the table has no code for -- with all-zero amplitude bits (value -4095: amplitude code
@@ -40,25 +39,33 @@ constexpr uint32_t kItPadValue = 0xF001u;
 // holds the EOB code under "size 13".
 constexpr uint32_t kItEobValue = 0xE001u;
 constexpr int kStageItemCap = 8 * 132;          // items a wave's LDS region holds (the tile's dead luma stash): 1056 >= 16 blocks x 65
+constexpr int kStageWords = 1152;               // ... and its size: the list is padded to whole passes of 128 items
 
 // Code table of k_tile_encode (LDS), built once on the host (quant_consts.cpp: build_code_table), independent of the quality.
-// Entry (row r, fb) at word kCodeLead + 32 r + fb:
+// Entry (row r, fb) at word kCodeLead + 33 r + fb (odd row stride: symbols of one size and different runs sit in different LDS banks):
 //   r   0: class D (fb selects the DC size, 12 = no code, 13 = EOB); r >= 1: AC symbol with run r - 1 (runs >= 16: the entry
 //       is that of run & 15 and carries the number of ZRL symbols in front of it, rle.c:99-103)
 //   fb  v_ffbh_i32 of twice the amplitude code: 31 - size, or -1 for a zero value (size 0)
 //   entry: bits 31..16 the Huffman code LEFT-ALIGNED, 15..8 code length + size, 6..5 ZRLs, 4..0 code length
 constexpr int kCodeLead = 32;
 constexpr int kCodeRows = 64;
-constexpr int kCodeWords = kCodeLead + kCodeRows * 32;               // 2080
+constexpr int kCodeRowStride = 33;
+constexpr int kCodeWords = kCodeLead + kCodeRows * kCodeRowStride;   // 2144
 constexpr uint32_t kZrlBits = 11, kZrlCode = 0x7F9u;                  // symbol 0xF0: '11111111001' (jpeg_tables.c:36-48)
 
-// Per-tile output of k_tile_encode in HBM: an 8-word record followed by the tile's bit string (MSB-first, from word 8):
-// every symbol of the tile except the DC of its first block.
+// Per-tile output of k_tile_encode in HBM: an 8-word record and the tile's bit string (MSB-first): every symbol of the tile
+// except the DC of its first block.
 //   record: {bits of the string, DC of the first block (absolute), DC of the last block, exact-order fallbacks,
 //            symbols (run/size symbols incl. ZRLs and the first DC), 0, 0, 0}
+// The record and the first 120 words of the string -- all of it for photo-like content -- form the tile's HEAD, 512 bytes in a
+// DENSE array (16 MB per 8192^2 picture: it stays in L2 / Infinity Cache between the two kernels); what lies beyond goes to a
+// sparse array reserved for the worst case (only touched bytes cost anything).  Round 2 kept everything in worst-case strides
+// of 8.7 KB per tile: every tile a DRAM row and a TLB entry of its own for ~100 useful bytes.
 constexpr int kTileRecWords = 8;
-constexpr int kTileStrCap = ((kTileBlocks * kMaxBlockBits + 31) / 32 + 2 + kTileRecWords + 63) / 64 * 64;   // words reserved per tile (1792)
-constexpr int kTileHeadWords = 128;             // record + the first 120 string words leave the kernel as ONE 8-byte-per-lane store
+constexpr int kTileHeadWords = 128;             // record + first string words: ONE 8-byte-per-lane store
+constexpr int kTileHeadStr = kTileHeadWords - kTileRecWords;   // 120
+constexpr int kTileOverCap = ((kTileBlocks * kMaxBlockBits + 31) / 32 + 2 + 63) / 64 * 64;   // words reserved per tile behind the head (1728)
+// (A dense array for the segments' strings as well was measured: k_finalize 38 -> 51 us per launch of eight pictures.)
 
 struct MfmaTables {
     uint32_t afrag[kAFragWords];   // kMfmaScale * LUT-product matrix as two integer-valued binary16 terms (lo 2^-11, hi), MFMA A-operand order
@@ -115,7 +122,8 @@ constexpr int kSegGroup = 4;
 
 struct TransformOutM {
     const MfmaTables *tables;   // device copy
-    uint32_t *tile_str;         // [num_tiles][kTileStrCap]: record + bit string of every tile
+    uint32_t *tile_head;        // [num_tiles][kTileHeadWords]: record + first string words of every tile
+    uint32_t *tile_over;        // [num_tiles][kTileOverCap]: string words from kTileHeadStr on (index w - kTileHeadStr)
     const uint32_t *code_tab;   // [kCodeWords] device copy of the code table
     uint32_t *tile_ctr;         // [64 groups][32 words]: word 0 = ticket counter of the group's tile hand-out; zero at launch
     uint32_t *tile_ctr_next;    // the set the NEXT launch on this context uses: zeroed by this launch
@@ -129,7 +137,7 @@ struct TransformOutM {
 int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream, void *const *ev = nullptr);
 
 struct MergeArgs {              // k_segment_merge: the tile strings of a segment -> ONE bit string per segment + its numbers
-    const uint32_t *tile_str;
+    const uint32_t *tile_head, *tile_over;
     const uint32_t *huff;           // [272] (len << 16) | code: AC by run/size symbol, then 16 DC sizes
     int32_t num_segs, segs_per_row, tiles_per_row;     // per image
     int32_t seg_begin, seg_end;     // segments this launch codes (whole images: 0, batch * num_segs)

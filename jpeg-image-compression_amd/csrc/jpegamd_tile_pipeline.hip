@@ -117,6 +117,18 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 #define TSTAMP(i) do { } while (0)
 #endif
 
+#ifndef JPEGAMD_TICKET_AT
+#define JPEGAMD_TICKET_AT 1           // where the next tile's ticket is requested: 0 top of the iteration, 1 behind the luma conversion, 2 behind the MFMAs
+#endif
+#ifndef JPEGAMD_STASH_LATE
+#define JPEGAMD_STASH_LATE 0
+#endif
+#ifndef JPEGAMD_THIRD_ALWAYS
+#define JPEGAMD_THIRD_ALWAYS 1
+#endif
+#ifndef JPEGAMD_PREPAD
+#define JPEGAMD_PREPAD 1
+#endif
 #ifndef JPEGAMD_TILE_GROUPS
 #define JPEGAMD_TILE_GROUPS 64
 #endif
@@ -137,13 +149,13 @@ struct TileSched {            // division-free launch geometry, filled by launch
 };
 
 // Appends of one group's sites to the staged list, branch-free: per site one compare that narrows EXEC to the lanes holding
-// a non-zero value, the SDWA add that writes 8 x the zigzag position into the value's upper half (the item format of
-// jpegamd_internal.h; 8 J is an inline constant for every J), the LDS write, the address increment (5 issue slots; the
-// compiler's version costs 4 slots for a site no lane uses and ~10, with a taken branch, for the others).  `addr` is the
-// byte address in LDS of the lane's next item, `zg` 8 x the zigzag position of the group's site 0; values are modified in place.
+// a non-zero value, the SDWA add that writes the zigzag position into the value's upper half (the item format of
+// jpegamd_internal.h), the LDS write, the address increment (5 issue slots; the compiler's version costs 4 slots for a site
+// no lane uses and ~10, with a taken branch, for the others).  `addr` is the byte address in LDS of the lane's next item,
+// `zg` the zigzag position of the group's site 0; values are modified in place.
 #define JPEGAMD_APPEND_SITE(V, J)                                                                                       \
     "v_cmpx_ne_u32_e32 0, %[" #V "]\n\t"                                                                                \
-    "v_add_u32_sdwa %[" #V "], %[zg], 8*" #J " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
+    "v_add_u32_sdwa %[" #V "], %[zg], " #J " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
     "ds_write_b32 %[addr], %[" #V "]\n\t"                                                                               \
     "v_add_u32_e32 %[addr], 4, %[addr]\n\t"                                                                            \
     "s_mov_b64 exec, %[save]\n\t"
@@ -176,7 +188,7 @@ __device__ __forceinline__ void append_group_lds(uint32_t &addr, int (&v)[8], ui
 // predecessor is always an item of the same block (its DC item, position 0, or the non-zero coefficient before it).
 //   amplitude code  w = v + (v >> 31)                     rle.c:24-35: v, or v - 1 when negative
 //   size            31 - v_ffbh_i32(2 w), -1 -> 0         rle.c:9-22 without the abs / zero special cases
-//   row             8 x gap to the predecessor = 8 x (run + 1); class D items (position 0) take row 0 whatever precedes them:
+//   row             gap to the predecessor = run + 1; class D items (position 0) take row 0 whatever precedes them:
 //                   min(gap, own position) -- a gap is never larger than the position, and a class D item's is 0
 __device__ __forceinline__ void code_item(uint32_t it, uint32_t prev, const uint32_t *tab /*LDS: the code table*/, uint32_t &e, uint32_t &bits) {
     const int v = (int)(short)(it & 0xFFFFu);
@@ -184,9 +196,9 @@ __device__ __forceinline__ void code_item(uint32_t it, uint32_t prev, const uint
     int fb;
     asm("v_ffbh_i32 %0, %1" : "=v"(fb) : "v"(x2));
     const uint32_t al = (uint32_t)x2 << (fb & 31);                            // amplitude bits, left-aligned
-    const uint32_t pos8 = it >> 16;
-    const uint32_t row8 = min(pos8 - (prev >> 16), pos8);
-    e = tab[kCodeLead + (int)(row8 << 2) + fb];
+    const uint32_t pos = it >> 16;
+    const uint32_t row = min(pos - (prev >> 16), pos);
+    e = tab[kCodeLead + (int)__umul24(row, (uint32_t)kCodeRowStride) + fb];
     bits = (e & 0xFFFF0000u) | (al >> (e & 31u));
 }
 
@@ -202,19 +214,20 @@ template <bool kTaps>
 __global__ __launch_bounds__(64 * kWavesT) __attribute__((amdgpu_waves_per_eu(JPEGAMD_TILE_WAVES, JPEGAMD_TILE_WAVES)))
 void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched sch) {
     __shared__ __attribute__((aligned(16))) uint32_t s_afrag[kAFragWords];
-    __shared__ float2 s_q[64];                 // (multiplier, threshold) by zigzag position
+    // s_qt[0..127]: (multiplier, tie threshold) by zigzag position; [128 + 16 h + G]: zero threshold of group G for lane half h
+    // (|acc| below it => every site of the group quantises to an unflagged 0), [132 + 16 h + G]: the largest tie threshold of the
+    // group's sites (fract(zc) above it => no site is flagged).  One layout with 64 bytes per lane half: one address register.
+    __shared__ __attribute__((aligned(16))) float s_qt[128 + 32];
     __shared__ float s_qstep[64];
     __shared__ float s_cos[64];
     __shared__ uint32_t s_zz[64];               // zigzag position -> raster index (exact-order path)
     __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][64];   // exact-order path: the 64 terms of one coefficient
-    __shared__ float s_grp[16];                // [group][h]: |acc| below [0..7] => every site of the group quantises to an unflagged 0;
-                                               // [8..15]: the largest tie threshold of the group's sites (fract(zc) above it => no site is flagged)
     // The tile's centred luma (binary16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
     // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
     // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
     // prefetched rows of the NEXT tile as well: ~40 % of a tile's time per event (tools/stamp_profile_tile.py).
     // After the exact-order phase the same words hold the tile's item list.
-    __shared__ __attribute__((aligned(16))) uint32_t s_pix[kWavesT][kStageItemCap];
+    __shared__ __attribute__((aligned(16))) uint32_t s_pix[kWavesT][kStageWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kWavesT][kWinWords];      // per wave: the tile's record + bit window; all zero between tiles
     __shared__ __attribute__((aligned(16))) uint32_t s_code[kCodeWords];
 #ifdef JPEGAMD_STAMPS
@@ -231,11 +244,11 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         for (int i = t; i < kCodeWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(s_code)[i] = csrc[i];
         for (int i = t; i < kWavesT * kWinWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(&s_win[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
         if (t < 64) {
-            s_q[t] = make_float2(out.tables->qmul[t], out.tables->qthr[t]);
+            s_qt[2 * t] = out.tables->qmul[t]; s_qt[2 * t + 1] = out.tables->qthr[t];
             s_qstep[t] = out.tables->qstep[t];
             s_cos[t] = kCosFM[t];
             s_zz[t] = kZZ[t];
-            if (t < 8) { s_grp[t] = out.tables->grp_thr[t]; s_grp[8 + t] = out.tables->flag_thr[t]; }
+            if (t < 8) { s_qt[128 + 16 * (t & 1) + (t >> 1)] = out.tables->grp_thr[t]; s_qt[132 + 16 * (t & 1) + (t >> 1)] = out.tables->flag_thr[t]; }
         }
     }
     __syncthreads();
@@ -247,8 +260,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     asm volatile("v_mov_b32 %0, %1" : "=v"(bias) : "s"(out.tables->bias));
     const LumaWeights lw = luma_weights(im.weights);
     const uint32_t luma_kc = 0xFFFF8000u;
-    const float2 *sq_lane = &s_q[8 * h];
-    const float *zthr_lds = &s_grp[h];                             // zero threshold of group G: [2 G], its largest tie threshold: [8 + 2 G]
+    const float *q_lane = &s_qt[16 * h];
 
     // Persistent waves: tile = first, first + stride, ...  The matrix image is loaded once per workgroup and the
     // NEXT tile's pixel rows are requested as soon as the current ones are converted, so their HBM latency
@@ -291,7 +303,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     if (bid == 0 && threadIdx.x < kTileGroups) out.tile_ctr_next[threadIdx.x * 32] = 0u;   // all of them: the next launch may form more groups
     const int first = (bid >> sch.grp_shift) * kWavesT + wave;
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
-    struct TileGeo { int img, by, tbx0, nblk, bx; bool interior; };
+    struct TileGeo { int img, by, tbx0, nblk; bool interior; };
     const auto geo = [&](int tile) {
         TileGeo g;
         g.img = 0;
@@ -306,7 +318,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         g.by = q;
         g.tbx0 = r * kTileBlocks;
         g.nblk = min(kTileBlocks, im.blocks_w - g.tbx0);
-        g.bx = g.tbx0 + min(b, g.nblk - 1);                     // idle columns shadow the last block
         g.interior = im.fast_ok && ((g.tbx0 + g.nblk) * 8 <= im.width) && (g.by * 8 + 8 <= im.height);
         return g;
     };
@@ -321,7 +332,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         const uint8_t *tb = im.batch_pixels[g.img] + (size_t)row_low * (size_t)im.row_stride + 24 * (size_t)g.tbx0;
         uint32_t hh = (uint32_t)h;
         asm volatile("" : "+v"(hh));
-        uint32_t off = __umul24((uint32_t)(g.bx - g.tbx0), 24u) + __umul24(im.bottom_up ? 7u - hh : hh, (uint32_t)im.row_stride);   // row_stride < 2^24
+        uint32_t off = __umul24((uint32_t)min(b, g.nblk - 1), 24u) + __umul24(im.bottom_up ? 7u - hh : hh, (uint32_t)im.row_stride);   // row_stride < 2^24
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             raw[s] = load_raw_row(reinterpret_cast<const uint32_t *>(tb + off));
@@ -340,10 +351,13 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 
 #pragma unroll 1
     for (int li = first; li < cur_hi;) {
-        const int by = tg.by, nblk = tg.nblk, bx = tg.bx;
+        const int by = tg.by, nblk = tg.nblk, bx = tg.tbx0 + min(b, tg.nblk - 1);     // idle columns shadow the last block
         const int py0 = by * 8, px0 = bx * 8;
         const bool active = b < nblk, interior = tg.interior;
         int nexact = 0;
+#if JPEGAMD_TICKET_AT == 0
+        const uint32_t ticket_v = ticket();
+#endif
         TSTAMP(0);   // loop overhead / geometry
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         f16x8 bfrag[4];
@@ -359,9 +373,17 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     bfrag[s][j] = (_Float16)(float)(luma_clamped(im, im.batch_pixels[tg.img], px0 + j, py0 + 2 * s + h) - 128);
         }
         TSTAMP(1);   // wait for the prefetched rows + luma
+#if !JPEGAMD_STASH_LATE
+        {
+        uint32_t sl;                           // (an opaque lane id: the stash addresses are not worth four registers across the whole loop)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl));
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&s_pix[wave][(2 * s + h) * 132 + b * 4]) = bfrag[s];
-        TSTAMP(2);   // issue of the next tile's loads
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&s_pix[wave][(2 * s + (sl >> 5)) * 132 + (sl & 31) * 4]) = bfrag[s];
+        }
+#endif
+#if JPEGAMD_TICKET_AT == 1
+        const uint32_t ticket_v = ticket();
+#endif
         if (kTaps && active && out.tap_y) {
             int8_t *ty = out.tap_y + ((size_t)by * im.blocks_w + bx) * 64;
 #pragma unroll
@@ -404,8 +426,21 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             }
         }
 
-        TSTAMP(3);   // MFMA
+        // the luma stash for the exact-order path goes to LDS behind the MFMAs' operand reads: its four 16-byte writes then
+        // overlap the matrix pipe instead of delaying it
+#if JPEGAMD_STASH_LATE
+        {
+        uint32_t sl;                           // (an opaque lane id: the stash addresses are not worth four registers across the whole loop)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&s_pix[wave][(2 * s + (sl >> 5)) * 132 + (sl & 31) * 4]) = bfrag[s];
+        }
+#endif
+        TSTAMP(2);
+        TSTAMP(3);   // MFMA, luma -> LDS
+#if JPEGAMD_TICKET_AT == 2
         const uint32_t ticket_v = ticket();
+#endif
         // ---- 3. quantise with the guard band, one GROUP of 8 sites at a time -----------------------
         // Site s = 16H + r of lane (h, b) holds zigzag position 16 * (s >> 3) + 8 * h + (s & 7): group G = s >> 3
         // covers zigzag 16G .. 16G + 15 across the two lanes of a block.  Every instruction of any wave costs one
@@ -429,14 +464,14 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 float m = fmaxf(fabsf(a8[0]), fabsf(a8[1]));
 #pragma unroll
                 for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(a8[j]));
-                gact[G] = __ballot(m >= zthr_lds[2 * G]) != 0ull;
+                gact[G] = __ballot(m >= q_lane[128 + G]) != 0ull;
             }
             if (gact[G]) {
                 float fr[8], th[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int st = 8 * G + j;
-                    const float2 q = sq_lane[16 * G + j];
+                    const float2 q = reinterpret_cast<const float2 *>(q_lane)[16 * G + j];
                     const float zc = fmaf(a8[j], q.x, bias);                // z + 0.5 + delta
                     n[st] = floor_to_int(zc);
                     fr[j] = __builtin_amdgcn_fractf(zc);
@@ -445,7 +480,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 // Flags are rare (0.4 per tile): one min tree over the fractions against the group's largest threshold decides
                 // for the whole wave whether the per-site compares (16 instructions) are needed at all.
                 const float fmin8 = fminf(fminf(__builtin_fminf(fr[0], fminf(fr[1], fr[2])), fminf(fr[3], fminf(fr[4], fr[5]))), fminf(fr[6], fr[7]));
-                if (__ballot(fmin8 <= zthr_lds[8 + 2 * G]) != 0ull)
+                if (__ballot(fmin8 <= q_lane[132 + G]) != 0ull)
                     flagbits |= shift_in_le8(0u, fr, th) << (8 * G);        // bit j: site 8G + j is within delta of a tie
             } else if (kTaps) {
 #pragma unroll
@@ -574,7 +609,10 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         // write, one address increment.  A list longer than the staging region (noise, very high qualities: up to 65 items
         // per block) is built and coded in two halves of 16 blocks each; the values are modified in place, each lane's in
         // the half its block belongs to.
-        uint32_t *const str = out.tile_str + (size_t)tile * kTileStrCap;
+        uint32_t *const head = out.tile_head + (size_t)tile * kTileHeadWords;
+        const auto str_word = [&](uint32_t g) -> uint32_t * {                 // word g of the tile's string: head, then the sparse reservation
+            return g < (uint32_t)kTileHeadStr ? head + kTileRecWords + g : out.tile_over + (size_t)tile * kTileOverCap + (g - (uint32_t)kTileHeadStr);
+        };
         uint32_t *const stage = &s_pix[wave][0];
         uint32_t *const win = &s_win[wave][0];
         const int nhalves = t_all <= (uint32_t)kStageItemCap ? 1 : 2;
@@ -582,17 +620,19 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         uint32_t cur_bits = 0, wbase = 0, nzrl = 0;          // bits of the tile's string so far; string words already in HBM; ZRL symbols
         uint32_t carry_item = 0;                             // the last item of the pass before
 #pragma unroll 1
-        for (int half = 0; half < nhalves; ++half) {
+        for (int half = 0; half < nhalves; ++half) {             // (one copy of the code: three inlined copies cost more in instruction fetch than the 32 live registers)
             const uint32_t list_base = half ? items_h0 : 0u;
             const uint32_t nitems = half ? t_all - items_h0 : items_h0;
             if (active && (nhalves == 1 || (b >> 4) == half)) {
                 const uint32_t stage_addr = (uint32_t)(uintptr_t)stage - list_base * 4u;      // LDS byte address (the low 32 bits of the flat one)
                 uint32_t addr = 0;
+                uint32_t hh8 = (uint32_t)h << 3;               // (opaque: else the four groups' positions are four more loop invariants, spilled)
+                asm volatile("" : "+v"(hh8));
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     if (!gact[G]) continue;
                     addr = stage_addr + (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
-                    const uint32_t zg = (uint32_t)(8 * (16 * G + 8 * h));
+                    const uint32_t zg = (uint32_t)(16 * G) + hh8;
                     if (G == 0) {
                         // site 0: the DC item (always stored) in lanes h == 0, zigzag 8 in lanes h == 1
                         uint32_t first_item = dc_item;
@@ -615,19 +655,37 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(kItEobValue) : "memory");
                 }
             }
+            // (everything the coder derives from the lane number comes from a lane id the compiler cannot trace to the kernel's own:
+            //  as loop invariants of the tile loop those values were spilled, and reloaded from scratch -- a vector memory
+            //  operation -- in the middle of the phases that are supposed to hide the next tile's row loads)
+            uint32_t cl;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(cl));
+#if JPEGAMD_PREPAD
+            {   // the list is padded to whole passes with padding items (no bits): the coder then needs no tail masks
+                uint32_t padv = kItPadValue;
+                asm volatile("" : "+v"(padv));                 // (not a register held across the whole tile loop)
+                const uint32_t pi0 = nitems + cl, pend = (nitems + (uint32_t)kPassItems - 1u) & ~(uint32_t)(kPassItems - 1);
+                if (pi0 < pend) stage[pi0] = padv;
+                if (pi0 + 64u < pend) stage[pi0 + 64u] = padv;
+            }
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the asm writes are invisible to the compiler's counters
             TSTAMP(8);   // appends
 
             // ---- 7. Huffman coding of the list (rle.c:83-123, huffman.c:145-188): two items per lane and pass ----
 #pragma unroll 1
             for (uint32_t base = 0; base < nitems; base += (uint32_t)kPassItems) {
+                const uint2 pair = *reinterpret_cast<const uint2 *>(&stage[base + 2u * cl]);
+#if JPEGAMD_PREPAD
+                const uint32_t ia = pair.x, ib = pair.y;
+#else
                 const uint32_t rem = nitems - base;
-                const uint2 pair = *reinterpret_cast<const uint2 *>(&stage[base + 2u * (uint32_t)lane]);
                 uint32_t ia = pair.x, ib = pair.y;
                 if (rem < (uint32_t)kPassItems) {                 // the list's last pass: the lanes beyond it code padding items (no bits)
-                    ia = 2u * (uint32_t)lane < rem ? ia : kItPadValue;
-                    ib = 2u * (uint32_t)lane + 1u < rem ? ib : kItPadValue;
+                    ia = 2u * cl < rem ? ia : kItPadValue;
+                    ib = 2u * cl + 1u < rem ? ib : kItPadValue;
                 }
+#endif
                 // the item in front of a lane's first item: the second item of the lane before (lane 0: the pass before)
                 const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_item, (int)ib, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
                 carry_item = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
@@ -650,10 +708,10 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     const uint32_t done = (cur_bits >> 5) - wbase;              // complete words in the window
                     if (done) {
                         const uint32_t part = win[kTileRecWords + done];
-                        for (uint32_t j = (uint32_t)lane; j < done; j += 64) str[kTileRecWords + wbase + j] = win[kTileRecWords + j];
+                        for (uint32_t j = cl; j < done; j += 64) *str_word(wbase + j) = win[kTileRecWords + j];
 #pragma unroll
-                        for (int i = 0; i < kWinWords / 64; ++i) win[i * 64 + lane] = 0u;
-                        if (lane == 0) win[kTileRecWords] = part;
+                        for (int i = 0; i < kWinWords / 64; ++i) win[i * 64 + cl] = 0u;
+                        if (cl == 0) win[kTileRecWords] = part;
                         wbase += done;
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // leave no store of a varying count pending
                     }
@@ -663,7 +721,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     // join the lane's two strings: (bits_a : bits_b >> len_a), <= 54 bits
                     const uint32_t hi = sa | __builtin_amdgcn_alignbit(0u, sb, la);
                     const uint32_t lo = __builtin_amdgcn_alignbit(sb, 0u, la);
-                    window_or(win, rel, hi, lo, __ballot((rel & 31u) + lab > 64u) != 0ull);
+                    window_or(win, rel, hi, lo, JPEGAMD_THIRD_ALWAYS ? true : (__ballot((rel & 31u) + lab > 64u) != 0ull));
                 } else {
                     // symbol by symbol, each with its ZRLs in front (huffman.c:158-188 codes them as ordinary symbols)
                     const auto with_zrl = [&](uint32_t bits, uint32_t z, uint32_t &hi, uint32_t &lo) {
@@ -686,24 +744,33 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 
         // ---- 8. record + string leave the kernel ----
         {
+            uint32_t cl;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(cl));
             const uint32_t nw = ((cur_bits + 31u) >> 5) - wbase;                // string words still in the window
-            const bool whole = wbase == 0u && nw <= (uint32_t)(kTileHeadWords - kTileRecWords);
+            const bool whole = wbase == 0u && nw <= (uint32_t)kTileHeadStr;
             if (__builtin_expect(!whole, 0)) {                                  // a long string: its last words go out one by one
-                for (uint32_t j = (uint32_t)lane; j < nw; j += 64) str[kTileRecWords + wbase + j] = win[kTileRecWords + j];
+                for (uint32_t j = cl; j < nw; j += 64) *str_word(wbase + j) = win[kTileRecWords + j];
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (lane == 0) {
-                *reinterpret_cast<uint4 *>(win) = make_uint4(cur_bits, (uint32_t)first_dc, (uint32_t)last_dc, (uint32_t)nexact);
-                *reinterpret_cast<uint4 *>(win + 4) = make_uint4(t_all + nzrl, 0u, 0u, 0u);
+            {   // the record: lane i < 5 writes word i (one 4-byte LDS write; 16-byte writes cost the LDS write path 13 cycles each)
+                uint32_t rv = cur_bits;
+                asm("v_writelane_b32 %0, %1, 1\n\tv_writelane_b32 %0, %2, 2\n\tv_writelane_b32 %0, %3, 3\n\tv_writelane_b32 %0, %4, 4"
+                    : "+v"(rv) : "s"(first_dc), "s"(last_dc), "s"(nexact), "s"(t_all + nzrl));
+                if (cl < 5) win[cl] = rv;
             }
-            // the closing store: record + the first 120 string words, 8 bytes per lane; lanes beyond the string fall to the
+            // the closing store: the tile's head -- record + the first 120 string words -- 8 bytes per lane; lanes beyond the string fall to the
             // descriptor's range check (whole 8-byte pieces: the window is zero behind the string)
             typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
             const uint32_t head_bytes = whole ? (((uint32_t)kTileRecWords + nw + 1u) & ~1u) * 4u : (uint32_t)kTileRecWords * 4u;
-            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(str, 0, head_bytes, 0x00020000);
-            const u32x2 piece = *reinterpret_cast<const u32x2 *>(&win[lane * 2]);
-            __builtin_amdgcn_raw_buffer_store_b64(piece, crsrc, (uint32_t)(lane * 8), 0, 0);
-            *reinterpret_cast<uint4 *>(&win[lane * 4]) = make_uint4(0u, 0u, 0u, 0u);       // the window is all zero again
+            const __amdgpu_buffer_rsrc_t crsrc = __builtin_amdgcn_make_buffer_rsrc(head, 0, head_bytes, 0x00020000);
+            const u32x2 piece = *reinterpret_cast<const u32x2 *>(&win[cl * 2]);
+            __builtin_amdgcn_raw_buffer_store_b64(piece, crsrc, cl * 8u, 0, 0);
+            // the window is all zero again: its first 64 words with one 4-byte write, the rest only when the string reached there
+            win[cl] = 0u;
+            if (__builtin_expect(!(wbase == 0u && nw + (uint32_t)kTileRecWords <= 64u), 0)) {
+#pragma unroll
+                for (int i = 1; i < kWinWords / 64; ++i) win[i * 64 + cl] = 0u;
+            }
         }
 #undef JPEGAMD_ACC
         TSTAMP(10);  // record, copy-out

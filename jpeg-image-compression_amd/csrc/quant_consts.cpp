@@ -117,7 +117,7 @@ void build_code_table(uint32_t words[kCodeWords]) {
                 const uint32_t run = (uint32_t)(r - 1);
                 e = entry(hw[((run & 15u) << 4) | size], size, run >> 4);
             }
-            words[kCodeLead + 32 * r + fb] = e;
+            words[kCodeLead + kCodeRowStride * r + fb] = e;
         }
 }
 

@@ -69,6 +69,10 @@ LARGE = [  # width, height, seed, kind
 # pointed at: the three rotating bench seeds each, so that bench.py's parity key resolves whichever step comes last.
 LARGE_Q = [(8192, 8192, seed, 0, q) for q in (10, 90) for seed in (1000, 1001, 1002)]
 LARGE_NOISE = [(8192, 8192, seed, 1) for seed in (1000, 1001, 1002)]
+# The 16 rotating 8192^2 inputs of bench.py's default step (seeds 1000..1015) and the first eight of them at Q=10 / Q=90: what
+# the -m gpu tests of the batched launch (8 images through one launch of each kernel) are hashed against.
+LARGE_BENCH = [(8192, 8192, seed, 0) for seed in range(1003, 1016)]
+LARGE_BENCH_Q = [(8192, 8192, seed, 0, q) for q in (10, 90) for seed in range(1003, 1008)]
 # BASELINE.json configs[3]: 64 independent 4096x4096 images, distinct seeds
 BATCH4096 = [(4096, 4096, 2000 + i, 0) for i in range(64)]
 
@@ -137,6 +141,10 @@ def extend_large(which: str):
             jobs += [(w, h, seed, kind, q, apps[q]) for (w, h, seed, kind, q) in LARGE_Q]
         if which in ("all", "noise"):
             jobs += [(w, h, seed, kind, 50, str(oracle.REF_APP)) for (w, h, seed, kind) in LARGE_NOISE]
+        if which in ("all", "bench"):
+            apps = {q: str(build_quality_ref(q, Path(td))) for q in (10, 90)}
+            jobs += [(w, h, seed, kind, 50, str(oracle.REF_APP)) for (w, h, seed, kind) in LARGE_BENCH]
+            jobs += [(w, h, seed, kind, q, apps[q]) for (w, h, seed, kind, q) in LARGE_BENCH_Q]
         big = {}
         with ProcessPoolExecutor(max_workers=3) as ex:           # ~1.3 GB per 8192^2 reference run
             for key, ent in ex.map(_one_large, jobs):
@@ -158,7 +166,7 @@ def extend_large(which: str):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true", help="also (re)generate large.json (minutes of CPU)")
-    ap.add_argument("--configs", choices=["all", "quality", "noise", "batch"],
+    ap.add_argument("--configs", choices=["all", "quality", "noise", "batch", "bench"],
                     help="only ADD the BASELINE configs[3]/[4] answers: 8192^2 at Q=10/90 and noise into large.json, "
                          "64 x 4096^2 into batch4096.json (the other files stay as they are)")
     args = ap.parse_args()

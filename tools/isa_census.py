@@ -6,7 +6,7 @@ import sys
 from collections import Counter
 
 src = open(sys.argv[1]).read()
-m = re.search(r"^_ZN7jpegamd16k_tile_transformILb0EEE.*?:\n(.*?)\n\s*s_endpgm", src, re.S | re.M)
+m = re.search(r"^_ZN7jpegamd13k_tile_encodeILb0EEE.*?:\n(.*?)\n\s*s_endpgm", src, re.S | re.M)
 body = m.group(1).splitlines()
 phase = "pre"
 cnt = {}

@@ -5,7 +5,7 @@ every other VALU form 4, MFMA 8 (issue), DPP / SDWA 4.  Straight-line count: eve
 import re, sys
 from collections import Counter, defaultdict
 src = open(sys.argv[1]).read()
-m = re.search(r"^_ZN7jpegamd16k_tile_transformILb0EEE.*?:\n(.*?)\n\s*s_endpgm", src, re.S | re.M)
+m = re.search(r"^_ZN7jpegamd13k_tile_encodeILb0EEE.*?:\n(.*?)\n\s*s_endpgm", src, re.S | re.M)
 FAST = {"v_add_u32","v_sub_u32","v_subrev_u32","v_xor_b32","v_and_b32","v_or_b32","v_mov_b32","v_add_f32","v_sub_f32","v_mul_f32","v_fmac_f32","v_fma_f32","v_mov_b64"}
 phase = "pre"; cyc = defaultdict(float); cnt = defaultdict(Counter)
 for line in m.group(1).splitlines():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-phase cycle shares of k_tile_transform from in-kernel s_memtime stamps (per wave, summed over its tiles).
+"""Per-phase cycle shares of k_tile_encode from in-kernel s_memtime stamps (per wave, summed over its tiles).
 Needs a diagnostic build:  make -C jpeg-image-compression_amd EXTRA_HIPFLAGS=-DJPEGAMD_STAMPS
 The stamps do not drain vmcnt, so memory overlap is as shipped; s_memtime ticks at 100 MHz on gfx950."""
 import ctypes as C
@@ -34,8 +34,10 @@ fn.restype = C.c_int32
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 rc = fn(enc._h, buf.ctypes.data, nwaves)
 assert rc == 0, rc
-names = ["loop/geometry", "wait rows + luma", "luma -> LDS", "mfma", "quantise", "exact fallback", "counts+scans", "ticket, row requests, appends, copy-out"]
-ph = buf[:, :8]                                                    # phase sums: slots 0..7 (8..11 hold the real-time stamps)
+names = ["loop/geometry", "wait rows + luma", "luma -> LDS", "mfma", "quantise", "exact fallback", "counts+scans", "ticket, geometry, row requests",
+         "appends", "coding", "record, copy-out"]
+NP = len(names)
+ph = buf[:, :NP]                                                   # phase sums: slots 0..10 (11..14 hold the real-time stamps and the cycle count)
 tot = ph.sum()
 print(f"waves {nwaves}, mean ticks per wave {ph.sum(axis=1).mean():.0f} (max {ph.sum(axis=1).max()})")
 for i, n in enumerate(names):
@@ -47,15 +49,15 @@ for i, n in enumerate(names):
     col = ph[:, i].astype(np.float64)
     print(f"  {n:26s} std {col.std():8.0f}  p99 {np.percentile(col, 99):8.0f}  max {col.max():8.0f}")
 ex = buf[:, 5].astype(np.float64)
-print("corr(total, exact) =", np.corrcoef(tw.reshape(-1), ex)[0, 1], " corr(total, appends) =", np.corrcoef(tw.reshape(-1), buf[:, 7].astype(np.float64))[0, 1])
+print("corr(total, exact) =", np.corrcoef(tw.reshape(-1), ex)[0, 1], " corr(total, coding) =", np.corrcoef(tw.reshape(-1), buf[:, 9].astype(np.float64))[0, 1])
 
-rt = buf[:, 8:11].astype(np.float64)
+rt = buf[:, 11:14].astype(np.float64)
 span = (rt[:, 2].max() - rt[:, 0].min()) / 100.0
 print(f"kernel span seen by the waves: {span:.2f} us; entry spread {(rt[:, 0].max() - rt[:, 0].min()) / 100.0:.2f} us; "
       f"prologue (entry -> loop) mean {(rt[:, 1] - rt[:, 0]).mean() / 100.0:.2f} us max {(rt[:, 1] - rt[:, 0]).max() / 100.0:.2f} us; "
       f"loop mean {(rt[:, 2] - rt[:, 1]).mean() / 100.0:.2f} us max {(rt[:, 2] - rt[:, 1]).max() / 100.0:.2f} us; "
       f"first wave done at {(rt[:, 2].min() - rt[:, 0].min()) / 100.0:.2f} us")
-clk = buf[:, 11].astype(np.float64) / np.maximum(rt[:, 2] - rt[:, 1], 1.0) * 0.1
+clk = buf[:, 14].astype(np.float64) / np.maximum(rt[:, 2] - rt[:, 1], 1.0) * 0.1
 print(f"shader clock inside the loop: mean {clk.mean():.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})")
 # end-of-kernel balance: when do the ticket groups (blockIdx & 63) and the XCDs (blockIdx % 8) run dry?
 blk = np.arange(nwaves) // 8
