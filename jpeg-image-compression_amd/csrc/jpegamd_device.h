@@ -109,6 +109,16 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int /*lane*/ 
     v += dpp_or_zero<0x143, 0xC>(v);                                  // row_bcast:31 into rows 2 and 3
     return v;
 }
+// maximum across the wave (DPP row_shr steps + row broadcasts, as the prefix sums above)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, dpp_or_zero<0x111>(v));
+    v = max(v, dpp_or_zero<0x112>(v));
+    v = max(v, dpp_or_zero<0x114>(v));
+    v = max(v, dpp_or_zero<0x118>(v));
+    v = max(v, dpp_or_zero<0x142, 0xA>(v));
+    v = max(v, dpp_or_zero<0x143, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ int wave_sum_i32(int v) {
     return __builtin_amdgcn_readlane((int)wave_incl_scan_u32((uint32_t)v), 63);
 }

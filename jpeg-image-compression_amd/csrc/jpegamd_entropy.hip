@@ -64,16 +64,20 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
         if (lane == 0 && tile_in_image > 0) prev_last = *(trec + 2 - kTileHeadWords);   // the tile before (of the same image): its last DC
     }
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-    u32x2 piece[kSegTiles];
-    // (lanes 60..63 of a head piece, and tiles beyond the segment, fall to the range checks: zeros)
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    // (tiles beyond the segment fall to the range checks: zeros.  Everything sits in the vector offset: the range check does
+    //  not see the scalar one.)
     const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(tbase), 0, ntiles * kTileHeadWords * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(a.tile_over + (size_t)tile0 * kTileOverCap), 0, ntiles * kTileOverCap * 4, 0x00020000);
+    // The strings, lane-parallel over the segment's tiles: lane (t = l >> 3, i = l & 7) takes words 32 k + 4 i .. + 3 of tile t's
+    // string in step k.  The first two steps (64 words: all of a photo-like tile) are requested before anything is known.
+    const uint32_t lt = (uint32_t)lane >> 3, li4 = ((uint32_t)lane & 7u) * 4u;
+    const int head_off = (int)((lt * (uint32_t)kTileHeadWords + (uint32_t)kTileRecWords + li4) * 4u);
+    u32x4 quad[2];
 #pragma unroll
-    for (int t = 0; t < kSegTiles; ++t)
-        piece[t] = __builtin_amdgcn_raw_buffer_load_b64(      // (everything in the vector offset: the range check does not see the scalar one)
-            hrsrc, lane < kTileHeadStr / 2 ? (int)((uint32_t)lane * 8u) + (t * kTileHeadWords + kTileRecWords) * 4 : 0x7FFFFFF0, 0, 0);
+    for (int k = 0; k < 2; ++k) quad[k] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, head_off + k * 128, 0, 0);
 
 #pragma unroll
     for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
@@ -148,38 +152,67 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
         }
     };
 
-    // The 16 pieces, in order.  A DC symbol is <= 20 bits: the lane that made it ORs it in.  A string is moved 128 words at
-    // a time: lane l holds words 2 l and 2 l + 1 of the piece; shifted by the piece's bit offset they land in three window
-    // words, the outer two shared with the neighbour lanes (ds_or).
-#pragma unroll
-    for (int t = 0; t < kSegTiles; ++t) {
-        if (t >= ntiles) break;
-        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)toff, t);
-        const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)dclen, t);
-        const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)rbits, t);
-        make_room(off, off + dl + min(sb, (uint32_t)(kPieceWords * 32)));
-        if (lane == t && dl) {
-            const uint32_t rel = off - wbase * 32u, wi = rel >> 5, sh = rel & 31u;
-            const unsigned long long s64 = ((unsigned long long)dcsym << (64u - dl)) >> sh;     // left-aligned at bit sh of a word pair
+    const uint32_t nwords_t = (rbits + 31u) >> 5;                                 // lane t < 8: words of tile t's string
+    const uint32_t max_words = (uint32_t)wave_max_u32(nwords_t);
+    if (__builtin_expect(seg_bits <= (uint32_t)((kSegBufWords - 8) * 32) && max_words <= (uint32_t)kTileHeadStr, 1)) {
+        // The whole segment fits the window and every string its tile's head (nearly always): all tiles at once.
+        const uint32_t my_start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lt * 4u), (int)(toff + dclen));   // bit offset of my tile's string
+        const uint32_t my_words = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lt * 4u), (int)nwords_t);
+        if (lane < ntiles) {                                          // the DC symbols: lane t, <= 20 bits each
+            const uint32_t wi = toff >> 5, sh = toff & 31u;
+            const unsigned long long s64 = ((unsigned long long)dcsym << (64u - dclen)) >> sh;     // left-aligned at bit sh of a word pair
             atomicOr(&win[wi], (uint32_t)(s64 >> 32));
             atomicOr(&win[wi + 1], (uint32_t)s64);
         }
-        const uint32_t nwords = (sb + 31u) >> 5;
-        u32x2 pc = piece[t];
-        for (uint32_t w0 = 0; w0 < nwords; w0 += w0 ? (uint32_t)kPieceWords : (uint32_t)kTileHeadStr) {
-            const uint32_t start = off + dl + w0 * 32u;                              // bit offset of the piece in the segment
-            if (w0) {                                                                // (only strings beyond the tile's head come here)
-                make_room(start, start + min(sb - w0 * 32u, (uint32_t)(kPieceWords * 32)));
-                pc = __builtin_amdgcn_raw_buffer_load_b64(orsrc, (int)((uint32_t)lane * 8u) + (t * kTileOverCap + (int)w0 - kTileHeadStr) * 4, 0, 0);
-            }
-            // (a piece's words beyond the string are not zero: mask by count)
-            const uint32_t left = min(nwords - w0, w0 ? (uint32_t)kPieceWords : (uint32_t)kTileHeadStr);
-            const uint32_t x0 = 2u * (uint32_t)lane < left ? pc[0] : 0u, x1 = 2u * (uint32_t)lane + 1u < left ? pc[1] : 0u;
-            const uint32_t rel = start - wbase * 32u, wi = (rel >> 5) + 2u * (uint32_t)lane, sh = rel & 31u;
-            if (2u * (uint32_t)lane < left) {
+        for (uint32_t k = 0; k * 32u < max_words; ++k) {
+            u32x4 q = k == 0 ? quad[0] : quad[1];
+            if (k >= 2) q = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, head_off + (int)k * 128, 0, 0);
+            const uint32_t j0 = k * 32u + li4;                        // my first word of this step
+            if (j0 < my_words) {
+                // words beyond the string are not zero in memory: mask by count
+                const uint32_t x0 = q[0], x1 = j0 + 1u < my_words ? q[1] : 0u, x2 = j0 + 2u < my_words ? q[2] : 0u, x3 = j0 + 3u < my_words ? q[3] : 0u;
+                const uint32_t rel = my_start + j0 * 32u, wi = rel >> 5, sh = rel & 31u;
                 atomicOr(&win[wi], __builtin_amdgcn_alignbit(0u, x0, sh));
                 atomicOr(&win[wi + 1], __builtin_amdgcn_alignbit(x0, x1, sh));
-                atomicOr(&win[wi + 2], __builtin_amdgcn_alignbit(x1, 0u, sh));
+                atomicOr(&win[wi + 2], __builtin_amdgcn_alignbit(x1, x2, sh));
+                atomicOr(&win[wi + 3], __builtin_amdgcn_alignbit(x2, x3, sh));
+                atomicOr(&win[wi + 4], __builtin_amdgcn_alignbit(x3, 0u, sh));
+            }
+        }
+    } else {
+        // The 16 pieces, in order (a segment that does not fit the window, or a tile whose string reaches beyond its head).  A DC symbol is <= 20 bits: the lane that made it ORs it in.  A string is moved 128 words at
+        // a time: lane l holds words 2 l and 2 l + 1 of the piece; shifted by the piece's bit offset they land in three window
+        // words, the outer two shared with the neighbour lanes (ds_or).
+    #pragma unroll
+        for (int t = 0; t < kSegTiles; ++t) {
+            if (t >= ntiles) break;
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)toff, t);
+            const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)dclen, t);
+            const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)rbits, t);
+            make_room(off, off + dl + min(sb, (uint32_t)(kPieceWords * 32)));
+            if (lane == t && dl) {
+                const uint32_t rel = off - wbase * 32u, wi = rel >> 5, sh = rel & 31u;
+                const unsigned long long s64 = ((unsigned long long)dcsym << (64u - dl)) >> sh;     // left-aligned at bit sh of a word pair
+                atomicOr(&win[wi], (uint32_t)(s64 >> 32));
+                atomicOr(&win[wi + 1], (uint32_t)s64);
+            }
+            const uint32_t nwords = (sb + 31u) >> 5;
+            u32x2 pc = __builtin_amdgcn_raw_buffer_load_b64(hrsrc, lane < kTileHeadStr / 2 ? (int)((uint32_t)lane * 8u) + (t * kTileHeadWords + kTileRecWords) * 4 : 0x7FFFFFF0, 0, 0);
+            for (uint32_t w0 = 0; w0 < nwords; w0 += w0 ? (uint32_t)kPieceWords : (uint32_t)kTileHeadStr) {
+                const uint32_t start = off + dl + w0 * 32u;                              // bit offset of the piece in the segment
+                if (w0) {                                                                // (only strings beyond the tile's head come here)
+                    make_room(start, start + min(sb - w0 * 32u, (uint32_t)(kPieceWords * 32)));
+                    pc = __builtin_amdgcn_raw_buffer_load_b64(orsrc, (int)((uint32_t)lane * 8u) + (t * kTileOverCap + (int)w0 - kTileHeadStr) * 4, 0, 0);
+                }
+                // (a piece's words beyond the string are not zero: mask by count)
+                const uint32_t left = min(nwords - w0, w0 ? (uint32_t)kPieceWords : (uint32_t)kTileHeadStr);
+                const uint32_t x0 = 2u * (uint32_t)lane < left ? pc[0] : 0u, x1 = 2u * (uint32_t)lane + 1u < left ? pc[1] : 0u;
+                const uint32_t rel = start - wbase * 32u, wi = (rel >> 5) + 2u * (uint32_t)lane, sh = rel & 31u;
+                if (2u * (uint32_t)lane < left) {
+                    atomicOr(&win[wi], __builtin_amdgcn_alignbit(0u, x0, sh));
+                    atomicOr(&win[wi + 1], __builtin_amdgcn_alignbit(x0, x1, sh));
+                    atomicOr(&win[wi + 2], __builtin_amdgcn_alignbit(x1, 0u, sh));
+                }
             }
         }
     }
