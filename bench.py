@@ -18,7 +18,7 @@ Workloads (`--workload`, default `auto`):
              distinct seeds (tests/golden/batch4096.json holds the compiled reference's answers for all 64), by default one
              launch per step; every finished bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
 Reference quantisation table (Q=50) unless --quality says otherwise; pixel rows resident in HBM; output = complete
-JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_transform -> k_entropy -> k_finalize) over the
+JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_encode -> k_segment_merge -> k_finalize) over the
 step's images.  Launches alternate over `--streams` encoder contexts / HIP streams (default 4) so the latency-bound tail
 kernels of one launch overlap the transform of the next; every step is still a complete encode.  With N > 1 every rank
 encodes its own images (weak scaling, no data-path collective inside the encode) and the finished bitstreams are
@@ -27,14 +27,15 @@ collected at rank 0 with one asynchronous RCCL gather per `--gather-every` image
 
 Extra objects on the JSON line:
   "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes of ONE launch (BMP rows read + JFIF
-                  bytes written, per image x images_per_launch) / SUM of the three kernels' durations / 8 TB/s.  Durations are HIP-event timed inside
-                  this run through the C-ABI's event ring: every kernel is launched with its own begin / end events
-                  on the stream it runs on (a kernel's own duration, as a kernel trace shows it); with several
-                  streams they come from a single-stream pass right after the timed region (kernels of different images
-                  overlap in the timed region): once right behind the region (`sustained`) and once 250 ms later (the
-                  headline figures; the state a kernel trace of `bench.py --streams 1` sees).  `dominant_frac` is the
-                  same bytes over k_tile_transform alone, `hbm_read_frac` the read bytes alone over the sum,
-                  `per_image_us` the sum divided by images_per_launch.
+                  bytes written, per image x images_per_launch) / SUM of the three kernels' durations / 8 TB/s.  Durations are
+                  HIP-event timed inside this run through the C-ABI's event ring -- every kernel launched with its own begin / end
+                  events on the stream it runs on (a kernel's own duration, as a kernel trace shows it) -- in SEPARATE single-stream
+                  passes behind the timed region, whose own launches carry no events: once right behind the region (`sustained`) and
+                  once 250 ms later (the headline figures; the state a kernel trace of `bench.py --streams 1` sees).
+                  `dominant_frac` is the same bytes over k_tile_encode alone, `hbm_read_frac` the read bytes alone over the sum,
+                  `per_image_us` the sum divided by images_per_launch, `one_image_per_launch` the literal configs[2] launch shape.
+  "configs3"      N > 1 (or --force-gather): a short leg of BASELINE configs[3] behind the main one -- 8 independent 4096^2 images
+                  per rank and step in one launch, every bitstream gathered at rank 0.
   "cpu_baseline"  the compiled reference natural_c (oracle/_ref), single thread, on a bounded sample: with its own
                   flags (no -O) and with -O2; rank 0, N == 1 only.
 """
@@ -82,6 +83,7 @@ def parse_args():
                     help="N > 1: images per rank carried by one gather to rank 0 (few, large collectives)")
     ap.add_argument("--cpu-sample-rows", type=int, default=8192,
                     help="rows of the first image the CPU baseline encodes (bounded sample)")
+    ap.add_argument("--configs3-steps", type=int, default=20, help="steps of the configs[3] leg behind the main workload (N > 1; 0 = none)")
     return ap.parse_args()
 
 
@@ -206,301 +208,337 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    workload = args.workload if args.workload != "auto" else "image8192"
-    B = args.images_per_launch or 8
-    if workload == "image8192":
-        w, h, ips = args.width or 8192, args.height or 8192, B
-        nrot = ROTATE if B == 1 else max(ROTATE, 2 * B)          # a launch reads B distinct pictures, two launches never the same ones
-        seeds = [1000 + rank * nrot + i for i in range(nrot)]
-    else:
-        w, h, ips = args.width or 4096, args.height or 4096, BATCH_PER_RANK
-        seeds = [2000 + rank * BATCH_PER_RANK + i for i in range(BATCH_PER_RANK)]
-    K, W = args.steps, args.warmup
-    inputs, stride, first_bmp = make_inputs(args, rank, torch, jpegamd, w, h, seeds)
-    nimg = len(inputs)
-    nstreams = max(1, args.streams)
-    encs = [jpegamd.Encoder(w, B * ((h + 7) // 8 * 8)) for _ in range(nstreams)]
-    cap = 4096 + w * h // 2 if args.kind != 1 and args.quality <= 75 else 4096 + 2 * w * h     # >10x the typical photo-like output
-    nbuf = max(2 * nstreams * B, nimg, B + 1)
-    outs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-    sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(nbuf)]
-    imgs = [jpegamd.Encoder.image(t.data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, args.quality) for t in inputs]
-    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
+    def measure(workload, K, W, images_per_launch, primary):
+        """One workload through warm-up, timed region and the per-kernel passes -> (JSON line fields on rank 0, parity_ok, first BMP)."""
+        B = images_per_launch
+        if workload == "image8192":
+            w, h, ips = args.width or 8192, args.height or 8192, B
+            nrot = ROTATE if B == 1 else max(ROTATE, 2 * B)          # a launch reads B distinct pictures, two launches never the same ones
+            seeds = [1000 + rank * nrot + i for i in range(nrot)]
+        else:
+            w, h, ips = args.width or 4096, args.height or 4096, BATCH_PER_RANK
+            seeds = [2000 + rank * BATCH_PER_RANK + i for i in range(BATCH_PER_RANK)]
+        inputs, stride, first_bmp = make_inputs(args, rank, torch, jpegamd, w, h, seeds)
+        nimg = len(inputs)
+        nstreams = max(1, args.streams)
+        encs = [jpegamd.Encoder(w, B * ((h + 7) // 8 * 8)) for _ in range(nstreams)]
+        cap = 4096 + w * h // 2 if args.kind != 1 and args.quality <= 75 else 4096 + 2 * w * h     # >10x the typical photo-like output
+        nbuf = max(2 * nstreams * B, nimg, B + 1)
+        outs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+        sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(nbuf)]
+        imgs = [jpegamd.Encoder.image(t.data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, args.quality) for t in inputs]
+        tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
 
-    # N > 1: the finished bitstreams are collected at rank 0, `gather_every` images per collective (few, large
-    # messages: each peer's records cross its own xGMI link to the root in one piece).  The record size is fixed
-    # before the timed region from the sizes the inputs actually produce (+5 %), agreed over all ranks.
-    gather = None
-    G = max(1, args.gather_every)
-    if dist is not None:
-        from jpegamd.sharding import BatchedStreamGather
-        biggest = 0
-        for im in imgs:
-            encs[0].encode_async(im, outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
-            biggest = max(biggest, int(encs[0].finish().jfif_bytes))
-        t = torch.tensor([biggest], dtype=torch.int64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        slot_bytes = ((int(t.item()) * 21 // 20 + 4096 + 255) // 256) * 256 + 8
-        gather = BatchedStreamGather(slot_bytes, G, torch.device("cuda", local_rank), dst=0, depth=2)
-        rec_ptrs = {}
-        for st_i in range(2 * G):
-            pl, sz = gather.record(st_i)
-            rec_ptrs[st_i] = (pl.data_ptr(), pl.numel(), sz.data_ptr(), sz)
-    last_image = [-1]
+        # N > 1: the finished bitstreams are collected at rank 0, `gather_every` images per collective (few, large
+        # messages: each peer's records cross its own xGMI link to the root in one piece).  The record size is fixed
+        # before the timed region from the sizes the inputs actually produce (+5 %), agreed over all ranks.
+        gather = None
+        G = max(1, args.gather_every)
+        if dist is not None:
+            from jpegamd.sharding import BatchedStreamGather
+            biggest = 0
+            for im in imgs:
+                encs[0].encode_async(im, outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
+                biggest = max(biggest, int(encs[0].finish().jfif_bytes))
+            t = torch.tensor([biggest], dtype=torch.int64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            slot_bytes = ((int(t.item()) * 21 // 20 + 4096 + 255) // 256) * 256 + 8
+            gather = BatchedStreamGather(slot_bytes, G, torch.device("cuda", local_rank), dst=0, depth=2)
+            rec_ptrs = {}
+            for st_i in range(2 * G):
+                pl, sz = gather.record(st_i)
+                rec_ptrs[st_i] = (pl.data_ptr(), pl.numel(), sz.data_ptr(), sz)
+        last_image = [-1]
 
-    def encode_launch(m):
-        """m-th launch of the run: images n = m * B .. m * B + B - 1 (image n of the run is picture n % nimg)."""
-        si = m % nstreams                                         # launches alternate over the streams / contexts
-        with torch.cuda.stream(tstreams[si]):
-            ns = list(range(m * B, m * B + B))
-            if gather is None:
-                optrs = [(outs[n % nbuf].data_ptr(), cap, sizes[n % nbuf].data_ptr()) for n in ns]
-            else:
-                for n in ns:
-                    if n % G < nstreams * B:                      # a stream's first write into this buffer: behind the
-                        gather.reserve(n)                         # collective that last read it
-                optrs = [rec_ptrs[n % (2 * G)][:3] for n in ns]
-            if B == 1:
-                encs[si].encode_async(imgs[ns[0] % nimg], optrs[0][0], optrs[0][1], optrs[0][2], True, tstreams[si].cuda_stream)
-            else:
-                encs[si].encode_batch_async([imgs[n % nimg] for n in ns], [o[0] for o in optrs], min(o[1] for o in optrs),
-                                            [o[2] for o in optrs], True, tstreams[si].cuda_stream)
-            if gather is not None and ns[-1] % G == G - 1:
-                commit(ns[-1], False)
-        last_image[0] = m * B + B - 1
+        def encode_launch(m):
+            """m-th launch of the run: images n = m * B .. m * B + B - 1 (image n of the run is picture n % nimg)."""
+            si = m % nstreams                                         # launches alternate over the streams / contexts
+            with torch.cuda.stream(tstreams[si]):
+                ns = list(range(m * B, m * B + B))
+                if gather is None:
+                    optrs = [(outs[n % nbuf].data_ptr(), cap, sizes[n % nbuf].data_ptr()) for n in ns]
+                else:
+                    for n in ns:
+                        if n % G < nstreams * B:                      # a stream's first write into this buffer: behind the
+                            gather.reserve(n)                         # collective that last read it
+                    optrs = [rec_ptrs[n % (2 * G)][:3] for n in ns]
+                if B == 1:
+                    encs[si].encode_async(imgs[ns[0] % nimg], optrs[0][0], optrs[0][1], optrs[0][2], True, tstreams[si].cuda_stream)
+                else:
+                    encs[si].encode_batch_async([imgs[n % nimg] for n in ns], [o[0] for o in optrs], min(o[1] for o in optrs),
+                                                [o[2] for o in optrs], True, tstreams[si].cuda_stream)
+                if gather is not None and ns[-1] % G == G - 1:
+                    commit(ns[-1], False)
+            last_image[0] = m * B + B - 1
 
-    def step(i):
-        for j in range(ips // B):
-            encode_launch(i * (ips // B) + j)
+        def step(i):
+            for j in range(ips // B):
+                encode_launch(i * (ips // B) + j)
 
-    def commit(n, force):
-        cur = torch.cuda.current_stream()
-        for sj in tstreams:                                       # the buffer's records were produced on all streams
-            if sj != cur:
-                cur.wait_event(sj.record_event())
-        gather.commit(n, force=force)
+        def commit(n, force):
+            cur = torch.cuda.current_stream()
+            for sj in tstreams:                                       # the buffer's records were produced on all streams
+                if sj != cur:
+                    cur.wait_event(sj.record_event())
+            gather.commit(n, force=force)
 
-    def drain():
-        if gather is not None and last_image[0] >= 0:
-            if last_image[0] % G != G - 1:
-                with torch.cuda.stream(tstreams[0]):
-                    commit(last_image[0], True)
-            gather.wait_all()
-        torch.cuda.synchronize()
+        def drain():
+            if gather is not None and last_image[0] >= 0:
+                if last_image[0] % G != G - 1:
+                    with torch.cuda.stream(tstreams[0]):
+                        commit(last_image[0], True)
+                gather.wait_all()
+                torch.cuda.synchronize()
+                # a stream that outgrew its slot (sized from a sample + 5 %) does not fail the buffer: exact-size second gather
+                oversized[0] += gather.settle(last_image[0], reencode)
+            torch.cuda.synchronize()
 
-    def check_capacity(where):
-        """The capacity status is sticky on the device: finish() reports an overflow of ANY encode since the last finish."""
-        for e in encs:
-            try:
-                e.finish()
-            except jpegamd.JpegAmdError as err:
-                if err.code == -1:                                # nothing pending on this context
-                    continue
-                raise RuntimeError(f"bench.py: an encode in the {where} did not fit its output buffer ({err})")
+        oversized = [0]
 
-    for i in range(W):
-        step(i)
-    drain()
-    if W:
-        check_capacity("warm-up")
-
-    n_timed = K * ips
-    n_launches = n_timed // B
-    per_ctx = (n_launches + nstreams - 1) // nstreams
-    for e in encs:
-        e.set_profiling(per_ctx)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(K):
-        step(W + i)
-    t_issued = time.perf_counter()                               # host-side cost of enqueueing the K steps
-    drain()
-    if dist is not None:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    last = (W + K) * ips - 1
-    last_ctx = (last // B) % nstreams
-    st = encs[last_ctx].finish()                                  # raises if ANY timed encode overflowed on that context
-    for si, e in enumerate(encs):
-        if si != last_ctx and n_launches > si:
-            e.finish()
-    if gather is not None:                                        # every record of the last buffers carries a plausible size
-        for k in range(min(2 * G, n_timed)):
-            n_bytes = int(rec_ptrs[k][3].item())
-            if not (0 < n_bytes <= rec_ptrs[k][1]):
-                raise RuntimeError(f"bench.py: gather record {k} holds {n_bytes} bytes (capacity {rec_ptrs[k][1]})")
-
-    def mean_profile(pairs):
-        prof = [e.profile(s) for e, n_calls in pairs for s in range(n_calls)]
-        return tuple(sum(getattr(p, f) for p in prof) / max(1, len(prof)) for f in ("ns_transform", "ns_entropy", "ns_pack", "ns_total"))
-
-    first_timed = W * ips // B
-    ov_tr, ov_en, ov_pk, ov_tot = mean_profile([(e, len([m for m in range(first_timed, first_timed + n_launches) if m % nstreams == si]))
-                                                 for si, e in enumerate(encs)])
-    # Kernel durations for the roofline.  The library launches every kernel with its own begin / end events
-    # (hipExtLaunchKernelGGL), so a duration is the kernel's own, as in a kernel trace -- but with several streams the
-    # kernels of different images share the GPU in the timed region and stretch.  A short single-stream pass over the
-    # same inputs gives each kernel alone (this is what rocprofv3 --stats sees for `bench.py --streams 1`).
-    # Two such passes: one right behind the timed region (the GPU still in the power / clock state of sustained load: the
-    # HBM-bound k_tile_transform runs ~15-20 % longer there, the other two kernels a little shorter) and one after a short
-    # idle.  `roofline` is built from the second, the state a kernel trace of `bench.py --streams 1` sees (its launch gaps
-    # keep the GPU a quarter idle); the first is reported beside it as `sustained`.
-    sustained, single_ns = None, None
-    P, SKIP = 70, 10                                          # the first SKIP launches of a pass (clock ramp after the idle) are not averaged
-
-    def single_stream_pass(nb):
-        """P launches of nb images each on stream 0 -> mean own durations of the three kernels (ns per launch)."""
-        encs[0].set_profiling(P)
-        torch.cuda.synchronize()
-        for i in range(P):
-            if nb == 1:
-                encs[0].encode_async(imgs[i % nimg], outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
-            else:
-                ns = [(i * nb + j) % nimg for j in range(nb)]
-                encs[0].encode_batch_async([imgs[n] for n in ns], [outs[j].data_ptr() for j in range(nb)], cap,
-                                           [sizes[j].data_ptr() for j in range(nb)], True, tstreams[0].cuda_stream)
-        torch.cuda.synchronize()
-        encs[0].finish()
-        prof = [encs[0].profile(s) for s in range(SKIP, P)]
-        return tuple(sum(getattr(p, f) for p in prof) / len(prof) for f in ("ns_transform", "ns_entropy", "ns_pack", "ns_total"))
-
-    if nstreams > 1:
-        h_tr, h_en, h_pk, _ = single_stream_pass(B)
-        sustained = {"transform_us": round(h_tr / 1e3, 2), "entropy_us": round(h_en / 1e3, 2), "pack_us": round(h_pk / 1e3, 2),
-                     "sum_kernels_us": round((h_tr + h_en + h_pk) / 1e3, 2), "measured": f"single-stream pass of {P - SKIP} launches right behind the timed region"}
-        time.sleep(args.roofline_idle_ms / 1e3)
-        ns_tr, ns_en, ns_pk, ns_tot = single_stream_pass(B)
-        roof_note = f"single-stream pass of {P - SKIP} launches, {args.roofline_idle_ms:.0f} ms after the timed region"
-    else:
-        ns_tr, ns_en, ns_pk, ns_tot = ov_tr, ov_en, ov_pk, ov_tot
-        roof_note = "timed region (single stream)"
-    if B > 1 and not args.no_one_image_pass:                   # the same three kernels over ONE image per launch, for comparison
-        single_ns = single_stream_pass(1)
-    ns_sum = ns_tr + ns_en + ns_pk                                # sum of the kernels' own durations (no launch gaps)
-
-    # parity spot check against the committed natural_c golden: the last image of the run (B = 1), or one more batched launch
-    # whose first picture has a golden (goldens exist for the first three seeds of rank 0) and whose other outputs must equal
-    # single-image encodes of the same pictures
-    batch_self_ok = True
-    if B == 1:
-        pick = last % nimg
-        encs[0].encode_async(imgs[pick], outs[1].data_ptr(), cap, sizes[1].data_ptr(), True, tstreams[0].cuda_stream)
-        encs[0].finish()
-        out_bytes = bytes(outs[1][: int(sizes[1].item())].cpu().numpy())
-    else:
-        pick = 0
-        def batched(order):
-            encs[0].encode_batch_async([imgs[j % nimg] for j in order], [outs[j].data_ptr() for j in range(B)], cap,
-                                       [sizes[j].data_ptr() for j in range(B)], True, tstreams[0].cuda_stream)
+        def reencode(n, payload, size):
+            encs[0].encode_async(imgs[n % nimg], payload.data_ptr(), payload.numel(), size.data_ptr(), True, tstreams[0].cuda_stream)
             encs[0].finish()
-            return [bytes(outs[j][: int(sizes[j].item())].cpu().numpy()) for j in range(B)]
-        batch_out = batched(list(range(B)))
-        rotated = batched([(j + 1) % B for j in range(B)])           # the same pictures at other positions of the launch
-        out_bytes = batch_out[0]
-        batch_self_ok = all(rotated[j] == batch_out[(j + 1) % B] for j in range(B))
-    parity, parity_ok = "unchecked", True
-    gold_file = ROOT / "tests" / "golden" / ("large.json" if workload == "image8192" else "batch4096.json")
-    if gold_file.exists() and rank == 0:
-        key = f"{w}x{h}_seed{seeds[pick]}_kind{args.kind}_q{args.quality}"
-        ent = json.loads(gold_file.read_text()).get(key)
-        if ent:
-            parity_ok = ent["sha256"] == hashlib.sha256(out_bytes).hexdigest() and ent["size"] == len(out_bytes)
-            parity = "sha256 == natural_c golden" if parity_ok else "MISMATCH vs natural_c golden"
-            if B > 1:
-                gold = json.loads(gold_file.read_text())
-                others = [gold.get(f"{w}x{h}_seed{seeds[j % nimg]}_kind{args.kind}_q{args.quality}") for j in range(1, B)]
-                n_gold = 1 + sum(1 for j, g in enumerate(others, 1) if g)
-                gold_ok = all(g is None or (g["sha256"] == hashlib.sha256(batch_out[j]).hexdigest()) for j, g in enumerate(others, 1))
-                parity_ok = parity_ok and gold_ok and batch_self_ok
-                parity = (f"sha256 == natural_c golden ({n_gold} of the {B} pictures of a batched launch have one; all {B} come out the same "
-                          "at other positions of the launch)") if parity_ok else "MISMATCH (batched launch vs natural_c golden / vs the same pictures at other positions)"
 
-    if gather is not None and rank == 0:
-        per_rank = gather.result(last)
-        used = last % G + 1
-        if len(per_rank) != world or any(s[:2] != b"\xff\xd8" or s[-2:] != b"\xff\xd9" for r in per_rank for s in r[:used]):
-            raise RuntimeError("gathered streams are not complete JFIF files")
-        if workload == "batch4096" and gold_file.exists() and args.kind == 0 and args.quality == 50:
-            gold = json.loads(gold_file.read_text())               # every gathered stream of the last buffer against the reference
-            for r in range(world):
-                for k in range(used):
-                    n = last - (used - 1) + k
-                    ent = gold.get(f"{w}x{h}_seed{2000 + r * BATCH_PER_RANK + n % nimg}_kind0_q50")
-                    if ent and hashlib.sha256(per_rank[r][k]).hexdigest() != ent["sha256"]:
-                        parity, parity_ok = f"MISMATCH vs natural_c golden (rank {r}, image {n})", False
+        def check_capacity(where):
+            """The capacity status is sticky on the device: finish() reports an overflow of ANY encode since the last finish."""
+            for e in encs:
+                try:
+                    e.finish()
+                except jpegamd.JpegAmdError as err:
+                    if err.code == -1:                                # nothing pending on this context
+                        continue
+                    if gather is not None and err.code == -8:         # a record outgrew its slot: drain()'s settle() collects it
+                        continue
+                    raise RuntimeError(f"bench.py: an encode in the {where} did not fit its output buffer ({err})")
 
+        for i in range(W):
+            step(i)
+        drain()
+        if W:
+            check_capacity("warm-up")
+
+        n_timed = K * ips
+        n_launches = n_timed // B
+        for e in encs:
+            e.set_profiling(0)                                        # the timed region's launches carry no events (plain hipLaunchKernelGGL)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(W + i)
+        t_issued = time.perf_counter()                               # host-side cost of enqueueing the K steps
+        drain()
+        if dist is not None:
+            dist.barrier()
+        t1 = time.perf_counter()
+        elapsed = t1 - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        last = (W + K) * ips - 1
+        last_ctx = (last // B) % nstreams
+        def finish_timed(e):
+            try:
+                return e.finish()                                     # raises if ANY timed encode overflowed on that context
+            except jpegamd.JpegAmdError as err:
+                if gather is not None and err.code in (-1, -8):       # (settle() has collected the oversized records already)
+                    return None
+                raise
+        st = finish_timed(encs[last_ctx])
+        for si, e in enumerate(encs):
+            if si != last_ctx and n_launches > si:
+                finish_timed(e)
+        if gather is not None:                                        # every record of the last buffers carries a plausible size
+            for k in range(min(2 * G, n_timed)):
+                n_bytes = int(rec_ptrs[k][3].item())
+                if n_bytes <= 0:
+                    raise RuntimeError(f"bench.py: gather record {k} holds {n_bytes} bytes (capacity {rec_ptrs[k][1]})")
+
+        # Kernel durations for the roofline.  The library launches every kernel with its own begin / end events
+        # (hipExtLaunchKernelGGL), so a duration is the kernel's own, as in a kernel trace -- but with several streams the
+        # kernels of different images share the GPU in the timed region and stretch.  A short single-stream pass over the
+        # same inputs gives each kernel alone (this is what rocprofv3 --stats sees for `bench.py --streams 1`).
+        # Two such passes: one right behind the timed region (the GPU still in the power / clock state of sustained load: the
+        # HBM-bound k_tile_transform runs ~15-20 % longer there, the other two kernels a little shorter) and one after a short
+        # idle.  `roofline` is built from the second, the state a kernel trace of `bench.py --streams 1` sees (its launch gaps
+        # keep the GPU a quarter idle); the first is reported beside it as `sustained`.
+        sustained, single_ns = None, None
+        P, SKIP = (70, 10) if primary else (30, 6)                                          # the first SKIP launches of a pass (clock ramp after the idle) are not averaged
+
+        def single_stream_pass(nb):
+            """P launches of nb images each on stream 0 -> mean own durations of the three kernels (ns per launch)."""
+            encs[0].set_profiling(P)
+            torch.cuda.synchronize()
+            for i in range(P):
+                if nb == 1:
+                    encs[0].encode_async(imgs[i % nimg], outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
+                else:
+                    ns = [(i * nb + j) % nimg for j in range(nb)]
+                    encs[0].encode_batch_async([imgs[n] for n in ns], [outs[j].data_ptr() for j in range(nb)], cap,
+                                               [sizes[j].data_ptr() for j in range(nb)], True, tstreams[0].cuda_stream)
+            torch.cuda.synchronize()
+            encs[0].finish()
+            prof = [encs[0].profile(s) for s in range(SKIP, P)]
+            return tuple(sum(getattr(p, f) for p in prof) / len(prof) for f in ("ns_transform", "ns_entropy", "ns_pack", "ns_total"))
+
+        if primary:
+            h_tr, h_en, h_pk, _ = single_stream_pass(B)
+            sustained = {"transform_us": round(h_tr / 1e3, 2), "merge_us": round(h_en / 1e3, 2), "finalize_us": round(h_pk / 1e3, 2),
+                         "sum_kernels_us": round((h_tr + h_en + h_pk) / 1e3, 2), "measured": f"single-stream pass of {P - SKIP} launches right behind the timed region"}
+            time.sleep(args.roofline_idle_ms / 1e3)
+        ns_tr, ns_en, ns_pk, ns_tot = single_stream_pass(B)
+        roof_note = (f"single-stream pass of {P - SKIP} launches with per-kernel events, {args.roofline_idle_ms:.0f} ms after the timed region "
+                     "(the timed region itself launches without events)")
+        if primary and B > 1 and not args.no_one_image_pass:       # the same three kernels over ONE image per launch: the literal configs[2] launch shape
+            single_ns = single_stream_pass(1)
+        ns_sum = ns_tr + ns_en + ns_pk                                # sum of the kernels' own durations (no launch gaps)
+
+        # parity spot check against the committed natural_c golden: the last image of the run (B = 1), or one more batched launch
+        # whose first picture has a golden (goldens exist for the first three seeds of rank 0) and whose other outputs must equal
+        # single-image encodes of the same pictures
+        batch_self_ok = True
+        if B == 1:
+            pick = last % nimg
+            encs[0].encode_async(imgs[pick], outs[1].data_ptr(), cap, sizes[1].data_ptr(), True, tstreams[0].cuda_stream)
+            encs[0].finish()
+            out_bytes = bytes(outs[1][: int(sizes[1].item())].cpu().numpy())
+        else:
+            pick = 0
+            def batched(order):
+                encs[0].encode_batch_async([imgs[j % nimg] for j in order], [outs[j].data_ptr() for j in range(B)], cap,
+                                           [sizes[j].data_ptr() for j in range(B)], True, tstreams[0].cuda_stream)
+                encs[0].finish()
+                return [bytes(outs[j][: int(sizes[j].item())].cpu().numpy()) for j in range(B)]
+            batch_out = batched(list(range(B)))
+            rotated = batched([(j + 1) % B for j in range(B)])           # the same pictures at other positions of the launch
+            out_bytes = batch_out[0]
+            batch_self_ok = all(rotated[j] == batch_out[(j + 1) % B] for j in range(B))
+        parity, parity_ok = "unchecked", True
+        gold_file = ROOT / "tests" / "golden" / ("large.json" if workload == "image8192" else "batch4096.json")
+        if gold_file.exists() and rank == 0:
+            key = f"{w}x{h}_seed{seeds[pick]}_kind{args.kind}_q{args.quality}"
+            ent = json.loads(gold_file.read_text()).get(key)
+            if ent:
+                parity_ok = ent["sha256"] == hashlib.sha256(out_bytes).hexdigest() and ent["size"] == len(out_bytes)
+                parity = "sha256 == natural_c golden" if parity_ok else "MISMATCH vs natural_c golden"
+                if B > 1:
+                    gold = json.loads(gold_file.read_text())
+                    others = [gold.get(f"{w}x{h}_seed{seeds[j % nimg]}_kind{args.kind}_q{args.quality}") for j in range(1, B)]
+                    n_gold = 1 + sum(1 for j, g in enumerate(others, 1) if g)
+                    gold_ok = all(g is None or (g["sha256"] == hashlib.sha256(batch_out[j]).hexdigest()) for j, g in enumerate(others, 1))
+                    parity_ok = parity_ok and gold_ok and batch_self_ok
+                    parity = (f"sha256 == natural_c golden ({n_gold} of the {B} pictures of a batched launch have one; all {B} come out the same "
+                              "at other positions of the launch)") if parity_ok else "MISMATCH (batched launch vs natural_c golden / vs the same pictures at other positions)"
+
+        if gather is not None and rank == 0:
+            per_rank = gather.result(last)
+            used = last % G + 1
+            if len(per_rank) != world or any(s[:2] != b"\xff\xd8" or s[-2:] != b"\xff\xd9" for r in per_rank for s in r[:used]):
+                raise RuntimeError("gathered streams are not complete JFIF files")
+            if workload == "batch4096" and gold_file.exists() and args.kind == 0 and args.quality == 50:
+                gold = json.loads(gold_file.read_text())               # every gathered stream of the last buffer against the reference
+                for r in range(world):
+                    for k in range(used):
+                        n = last - (used - 1) + k
+                        ent = gold.get(f"{w}x{h}_seed{2000 + r * BATCH_PER_RANK + n % nimg}_kind0_q50")
+                        if ent and hashlib.sha256(per_rank[r][k]).hexdigest() != ent["sha256"]:
+                            parity, parity_ok = f"MISMATCH vs natural_c golden (rank {r}, image {n})", False
+
+        if rank != 0:
+            return None, parity_ok, None
+
+        mpx = w * h / 1e6
+        read_bytes = stride * h
+        algo_bytes = read_bytes + len(out_bytes)
+        launch_bytes = algo_bytes * B                                 # algorithmic bytes of ONE launch of each kernel (B images; the last image's size stands for all)
+        traffic, traffic_note = None, None
+        tf = ROOT / "profiles" / "hbm_traffic.json"
+        if tf.exists():
+            try:
+                ent = json.loads(tf.read_text()).get(f"{w}x{h}_kind{args.kind}", {})
+                if ent.get("pipeline_bytes_per_image"):
+                    traffic = ent["pipeline_bytes_per_image"] * B
+                    traffic_note = ("not measured in this run: " + ent.get("how", "profiles/hbm_traffic.json")
+                                    + f"; per image x {B} images per launch")
+            except Exception:
+                traffic = None
+        one = None
+        if single_ns:
+            one = {"transform_us": round(single_ns[0] / 1e3, 2), "merge_us": round(single_ns[1] / 1e3, 2), "finalize_us": round(single_ns[2] / 1e3, 2),
+                   "sum_kernels_us": round(sum(single_ns[:3]) / 1e3, 2), "achieved": round(algo_bytes / sum(single_ns[:3]), 1),
+                   "frac": round(algo_bytes / sum(single_ns[:3]) / HBM_PEAK_GBS, 4),
+                   "measured": f"single-stream pass of {P - SKIP} single-image launches (the literal BASELINE configs[2] launch shape) behind the batched one"}
+        if workload == "batch4096":
+            what = " (BASELINE configs[3]: batch of 64 at 8 ranks)"
+        elif B == 1:
+            what = " (BASELINE configs[2])"
+        else:
+            what = (f" ({B} images per launch of each kernel: an extension of BASELINE configs[2], whose literal shape -- one image per launch -- "
+                    "is roofline.one_image_per_launch)")
+        line = {
+            "metric": "Mpixels/s encode (BMP -> grayscale baseline JPEG, bit-exact vs natural_c)",
+            "value": round(world * ips * mpx * K / elapsed, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 in, f32 DCT, int16 coefficients",
+            "data": "synthetic",
+            "config": {"workload": f"{w}x{h} synthetic RGB BMP (kind {args.kind}), Q={args.quality}, {ips} image(s)/step/rank, "
+                                   f"{nimg} distinct inputs/rank" + what,
+                       "images_per_step": world * ips,
+                       "images_per_launch": B,
+                       "streams_per_rank": nstreams,
+                       "parallelism": f"dp{world} (independent images per rank"
+                                      + (", async RCCL gather of bitstreams to rank 0)" if dist is not None else ")")},
+            "roofline": {"bound": "hbm", "kernel": "k_tile_encode + k_segment_merge + k_finalize (sum of durations, SURVEY.md 8d)",
+                         "achieved": round(launch_bytes / ns_sum, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(launch_bytes / ns_sum / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes": launch_bytes, "images_per_launch": B,
+                         "hbm_read_frac": round(read_bytes * B / ns_sum / HBM_PEAK_GBS, 4),
+                         "dominant_kernel": "k_tile_encode", "dominant_frac": round(launch_bytes / ns_tr / HBM_PEAK_GBS, 4),
+                         "per_image_us": round(ns_sum / B / 1e3, 2),
+                         "kernel_us": round(ns_tr / 1e3, 2), "merge_us": round(ns_en / 1e3, 2), "finalize_us": round(ns_pk / 1e3, 2),
+                         "sum_kernels_us": round(ns_sum / 1e3, 2), "first_to_last_event_us": round(ns_tot / 1e3, 2),
+                         "throughput_frac": round(algo_bytes * ips / (elapsed / K * 1e9) / HBM_PEAK_GBS, 4),
+                         "measured": roof_note,
+                         "one_image_per_launch": one,
+                         "sustained": (dict(sustained, frac=round(launch_bytes / (sustained["sum_kernels_us"] * 1e3) / HBM_PEAK_GBS, 4)) if sustained else None)},
+            "host_issue_us_per_step": round((t_issued - t0) / K * 1e6, 2),
+            "jfif_bytes": len(out_bytes),
+            "exact_fallbacks_per_image": (int(st.exact_fallbacks) // B if st is not None else None),       # (the counter sums over the launch's B images)
+            "parity": parity,
+        }
+        if gather is not None:
+            line["gather"] = {"images_per_collective": G, "record_bytes": slot_bytes, "collectives": gather.collectives,
+                              "records_beyond_their_slot": oversized[0]}
+        return line, parity_ok, first_bmp
+
+    workload = args.workload if args.workload != "auto" else "image8192"
+    line, parity_ok, first_bmp = measure(workload, args.steps, args.warmup, args.images_per_launch or 8, True)
+    # N > 1: BASELINE configs[3] (the batch of 64 4096^2 images at 8 ranks) as a short second leg, so that a multi-GPU run of the
+    # default command reports the gathered-batch configuration as well
+    if dist is not None and workload == "image8192" and args.configs3_steps > 0 and not (args.width or args.height):
+        c3, c3_ok, _ = measure("batch4096", args.configs3_steps, 5, 8, False)
+        parity_ok = parity_ok and c3_ok
+        if rank == 0:
+            line["configs3"] = {k: c3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "jfif_bytes", "parity")}
+            line["configs3"]["roofline"] = {k: c3["roofline"][k] for k in ("frac", "achieved", "sum_kernels_us", "per_image_us", "images_per_launch")}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return 0
-
-    mpx = w * h / 1e6
-    read_bytes = stride * h
-    algo_bytes = read_bytes + len(out_bytes)
-    launch_bytes = algo_bytes * B                                 # algorithmic bytes of ONE launch of each kernel (B images; the last image's size stands for all)
-    traffic = None
-    tf = ROOT / "profiles" / "hbm_traffic.json"
-    if tf.exists():
-        try:
-            traffic = json.loads(tf.read_text()).get(f"{w}x{h}_kind{args.kind}", {}).get("pipeline_bytes_per_image")
-        except Exception:
-            traffic = None
-    line = {
-        "metric": "Mpixels/s encode (BMP -> grayscale baseline JPEG, bit-exact vs natural_c)",
-        "value": round(world * ips * mpx * K / elapsed, 1),
-        "unit": "Mpixels/s",
-        "n_gpus": world,
-        "steps": K,
-        "warmup": W,
-        "ms_per_step": round(elapsed / K * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u8 in, f32 DCT, int16 coefficients",
-        "data": "synthetic",
-        "config": {"workload": (f"{w}x{h} synthetic RGB BMP (kind {args.kind}), Q={args.quality}, {ips} image(s)/step/rank, "
-                                f"{nimg} distinct inputs/rank" + (" (BASELINE configs[3]: batch of 64 at 8 ranks)" if workload == "batch4096" else
-                                                                   " (BASELINE configs[2])")),
-                   "images_per_step": world * ips,
-                   "images_per_launch": B,
-                   "streams_per_rank": nstreams,
-                   "parallelism": f"dp{world} (independent images per rank"
-                                  + (", async RCCL gather of bitstreams to rank 0)" if dist is not None else ")")},
-        "roofline": {"bound": "hbm", "kernel": "k_tile_transform + k_entropy + k_finalize (sum of durations, SURVEY.md 8d)",
-                     "achieved": round(launch_bytes / ns_sum, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(launch_bytes / ns_sum / HBM_PEAK_GBS, 4), "traffic": (traffic * B if traffic else None),
-                     "algorithmic_bytes": launch_bytes, "images_per_launch": B,
-                     "hbm_read_frac": round(read_bytes * B / ns_sum / HBM_PEAK_GBS, 4),
-                     "dominant_kernel": "k_tile_transform", "dominant_frac": round(launch_bytes / ns_tr / HBM_PEAK_GBS, 4),
-                     "per_image_us": round(ns_sum / B / 1e3, 2),
-                     "kernel_us": round(ns_tr / 1e3, 2), "entropy_us": round(ns_en / 1e3, 2), "pack_us": round(ns_pk / 1e3, 2),
-                     "sum_kernels_us": round(ns_sum / 1e3, 2), "first_to_last_event_us": round(ns_tot / 1e3, 2),
-                     "throughput_frac": round(algo_bytes * ips / (elapsed / K * 1e9) / HBM_PEAK_GBS, 4),
-                     "measured": roof_note,
-                     "one_image_per_launch": ({"transform_us": round(single_ns[0] / 1e3, 2), "entropy_us": round(single_ns[1] / 1e3, 2),
-                                               "pack_us": round(single_ns[2] / 1e3, 2), "sum_kernels_us": round(sum(single_ns[:3]) / 1e3, 2),
-                                               "frac": round(algo_bytes / sum(single_ns[:3]) / HBM_PEAK_GBS, 4),
-                                               "measured": f"single-stream pass of {P - SKIP} single-image launches behind the batched one"}
-                                              if single_ns else None),
-                     "sustained": (dict(sustained, frac=round(launch_bytes / (sustained["sum_kernels_us"] * 1e3) / HBM_PEAK_GBS, 4)) if sustained else None),
-                     "overlapped_us": {"transform": round(ov_tr / 1e3, 2), "entropy": round(ov_en / 1e3, 2),
-                                       "pack": round(ov_pk / 1e3, 2), "total": round(ov_tot / 1e3, 2)}},
-        "host_issue_us_per_step": round((t_issued - t0) / K * 1e6, 2),
-        "jfif_bytes": len(out_bytes),
-        "exact_fallbacks_per_image": int(st.exact_fallbacks),
-        "parity": parity,
-    }
+        return 0 if parity_ok else 3
     if world == 1 and not args.no_cpu_baseline:
         try:
-            line["cpu_baseline"] = cpu_baseline(first_bmp, args, w, h)
+            line["cpu_baseline"] = cpu_baseline(first_bmp, args, args.width or 8192 if workload == "image8192" else args.width or 4096,
+                                                args.height or 8192 if workload == "image8192" else args.height or 4096)
         except Exception as e:                                    # a missing checker must not hide the GPU number
             line["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(line), file=json_out, flush=True)

@@ -40,7 +40,9 @@ struct JpegAmdEncoder {
     MfmaTables *tables_dev = nullptr;
     MfmaTables *tables_host = nullptr;          // this context's own staging copy (contexts may be driven from different threads)
     uint32_t *tile_head = nullptr, *tile_over = nullptr, *tile_ctr = nullptr, *code_tab = nullptr;
-    int ctr_set = 0;                    // which half of tile_ctr the next k_tile_transform launch uses
+    int ctr_set = 0;                    // which half of tile_ctr the next k_tile_encode launch uses
+    int poison_tile = -1;               // jpegamd_debug_poison_tile_record: the next encode overwrites this tile's record word 0 ...
+    uint32_t poison_value = 0;          // ... with this value, between k_tile_encode and k_segment_merge
     unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
     // cached constants
     int cur_quality = -1;
@@ -274,7 +276,9 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     for (int i = 0; i < kMaxBatch; ++i) d->batch_pixels[i] = d->pixels;
     const uint64_t tpi = 0x100000000ull / (uint64_t)d->num_tiles;
     d->tpi_magic = tpi > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tpi;
-    d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0) ? 1 : 0;
+    // the dword loader multiplies the row stride by a 24-bit multiply (and keeps a tile's eight row offsets in 32 bits): wider
+    // strides -- a region of interest inside a huge buffer -- take the clamped byte loader, whose addresses are 64-bit
+    d->fast_ok = ((((uintptr_t)img->pixels) & 3u) == 0 && (img->row_stride & 3) == 0 && img->row_stride < (1 << 24)) ? 1 : 0;
     if (e && !context_fits(e, img->width, img->height)) return JPEGAMD_ERR_TOO_LARGE;
     return JPEGAMD_OK;
 }
@@ -293,6 +297,12 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     to.tile_ctr_next = e->tile_ctr + (e->ctr_set ? 0 : 64 * 32);
     if (int err = launch_tile_transform(im, to, taps, stream, (ev && !taps) ? (void *const *)ev : nullptr)) return err;
     if (im.tile_end > im.tile_begin) e->ctr_set ^= 1;      // (an empty range launches nothing)
+    if (e->poison_tile >= 0) {                             // fault injection for the tests: a corrupt record must end in a status code
+        if (e->poison_tile < e->max_tiles &&
+            hipMemsetD32Async((hipDeviceptr_t)(e->tile_head + (size_t)e->poison_tile * kTileHeadWords), (int)e->poison_value, 1, (hipStream_t)stream) != hipSuccess)
+            return (int)hipErrorUnknown;
+        e->poison_tile = -1;
+    }
     MergeArgs ea;
     std::memset(&ea, 0, sizeof(ea));
     ea.tile_head = e->tile_head; ea.tile_over = e->tile_over;
@@ -535,6 +545,15 @@ extern "C" int32_t jpegamd_debug_stages(JpegAmdEncoder *e, const JpegAmdImage *i
     if (rc) return rc;
     if (launch_transform_and_entropy(e, im, true, y_centered, quant_zigzag, exact_mask, nullptr)) return JPEGAMD_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(nullptr));
+    return JPEGAMD_OK;
+}
+
+// Fault injection (tests): the next encode on this context finds `value` in word 0 (the string's bit count) of tile `tile`'s
+// record when k_segment_merge reads it.  Not part of the public header.
+extern "C" int32_t jpegamd_debug_poison_tile_record(JpegAmdEncoder *e, int32_t tile, uint32_t value) {
+    if (!e || tile < 0 || tile >= e->max_tiles) return JPEGAMD_ERR_ARG;
+    e->poison_tile = tile;
+    e->poison_value = value;
     return JPEGAMD_OK;
 }
 

@@ -110,7 +110,9 @@ class BatchedStreamGather:
         self._recv = [[torch.empty(n, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.is_dst else None
                       for _ in range(depth)]
         self._work = [None] * depth
+        self._extra = [dict() for _ in range(depth)]        # dst: {(rank, record): bytes} of the records collected by settle()
         self.collectives = 0
+        self.device = device
 
     def _where(self, step: int) -> Tuple[int, int]:
         return (step // self.slots) % self.depth, step % self.slots
@@ -141,6 +143,51 @@ class BatchedStreamGather:
             if w is not None:
                 w.wait()
 
+    def settle(self, step: int, reencode=None) -> int:
+        """Collective (EVERY rank calls it, once the gather of the buffer holding `step` was waited for): a record whose
+        stream did not fit its slot -- the encoder stores the would-be byte count even then, so its size field exceeds
+        slot_bytes - 8 -- does not fail the buffer: its rank encodes that image again, `reencode(record_step, payload_tensor,
+        size_tensor)`, into a buffer of the exact size, and ONE more gather collects all of them.  `result()` then returns the
+        complete streams.  Returns the number of such records over all ranks; 0 (the usual case) costs one small all-reduce."""
+        b, _ = self._where(step)
+        base = (step // self.slots) * self.slots
+        cap = self.slot_bytes - 8
+        sizes = self._stage[b].view(self.slots, self.slot_bytes)[:, cap:].contiguous().view(torch.int64).cpu().reshape(-1)
+        mine = [k for k in range(self.slots) if int(sizes[k]) > cap]
+        agree = torch.tensor([len(mine), max([int(sizes[k]) for k in mine], default=0)], dtype=torch.int64, device=self.device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=self.group)
+        count, biggest = int(agree[0].item()), int(agree[1].item())
+        self._extra[b] = dict()
+        if count == 0:
+            return 0
+        if reencode is None:
+            raise RuntimeError(f"{count} record(s) did not fit their slot of {cap} bytes and no reencode callback was given")
+        rec_bytes = (biggest + 7) // 8 * 8 + 16                       # payload, its byte count, the record's index in the buffer
+        ext = torch.zeros(count * rec_bytes, dtype=torch.uint8, device=self.device)
+        tail = ext.view(count, rec_bytes)[:, rec_bytes - 16:]
+        for j in range(count):
+            idx = tail[j, 8:].view(torch.int64)
+            idx.fill_(-1)                                             # (unused rows of a rank with fewer offenders)
+        for j, k in enumerate(mine):
+            row = ext[j * rec_bytes:(j + 1) * rec_bytes]
+            reencode(base + k, row[:rec_bytes - 16], row[rec_bytes - 16:rec_bytes - 8].view(torch.int64))
+            row[rec_bytes - 8:].view(torch.int64).fill_(k)
+        recv = [torch.empty_like(ext) for _ in range(self.world)] if self.is_dst else None
+        dist.gather(ext, recv, dst=self.dst, group=self.group)
+        self.collectives += 1
+        if self.is_dst:
+            for r in range(self.world):
+                buf = recv[r].cpu().view(count, rec_bytes)
+                for j in range(count):
+                    n = int(buf[j, rec_bytes - 16:rec_bytes - 8].view(torch.int64).item())
+                    k = int(buf[j, rec_bytes - 8:].view(torch.int64).item())
+                    if k < 0:
+                        continue
+                    if not (0 < n <= rec_bytes - 16):
+                        raise RuntimeError(f"re-encoded record {k} of rank {r} holds {n} bytes (capacity {rec_bytes - 16})")
+                    self._extra[b][(r, k)] = bytes(buf[j, :n].numpy())
+        return sum(1 for _ in mine) if not self.is_dst else len(self._extra[b])
+
     def result(self, step: int) -> List[List[bytes]]:
         """On dst, after wait_all() and a device synchronise: per rank, the streams of the buffer holding `step`."""
         if not self.is_dst:
@@ -153,8 +200,11 @@ class BatchedStreamGather:
             for k in range(self.slots):
                 rec = buf[k * self.slot_bytes:(k + 1) * self.slot_bytes]
                 n = int(rec[self.slot_bytes - 8:].view(torch.int64).item())
+                if (r, k) in self._extra[b]:                          # it did not fit its slot: collected by settle()
+                    streams.append(self._extra[b][(r, k)])
+                    continue
                 if n < 0 or n > self.slot_bytes - 8:
-                    raise RuntimeError(f"gathered size {n} outside the record ({self.slot_bytes - 8})")
+                    raise RuntimeError(f"gathered size {n} outside the record ({self.slot_bytes - 8}); call settle() on every rank")
                 streams.append(bytes(rec[:n].numpy()))
             out.append(streams)
         return out

@@ -206,6 +206,8 @@ def test_large_configs_against_reference_hashes(jpegamd, dev):
     for key, e in large.items():                       # configs[1], [2], [4] (Q = 10 / 50 / 90 on 8192^2) and the noise stress
         dims, seed, kind, q = key.split("_")
         w, h = (int(x) for x in dims.split("x"))
+        if w == 8192 and int(seed[4:]) > 1002:         # (the other bench seeds go through the batched launch, below)
+            continue
         bmp = jpegamd.synth_bmp(w, h, int(seed[4:]), int(kind[4:]), 0)
         assert hashlib.sha256(bmp).hexdigest() == e["bmp_sha256"]
         got, st = device_encode(jpegamd, enc, bmp, dev, quality=int(q[1:]), cap=4096 + 2 * w * h)
@@ -215,6 +217,92 @@ def test_large_configs_against_reference_hashes(jpegamd, dev):
         body = got[328:-2]
         assert b"\xff" not in body.replace(b"\xff\x00", b""), "an unstuffed 0xFF inside the entropy-coded segment"
         assert st.entropy_bits > 0 and (st.entropy_bits + 7) // 8 + st.stuffed_bytes == len(body)
+
+
+def test_batched_launch_at_full_size_against_reference_hashes(jpegamd, dev):
+    """The entry point bench.py times, at the sizes it times: jpegamd_encode_batch_async with EIGHT images through ONE launch of
+    each kernel.  The 16 rotating 8192^2 bench inputs (seeds 1000..1015, two launches at Q=50), the first eight of them at Q=10 and
+    at Q=90 (one launch each; BASELINE configs[4]), and eight 4096^2 images of configs[3] (seeds 2000..2007) in one launch: every
+    output hashed against what the compiled reference (natural_c's own flags; table-patched for Q != 50) wrote for that image
+    alone -- the DC chain (rle.c:59-70), the bit offsets and the stuffing (huffman.c:26-81) restart with every image."""
+    large = json.loads((GOLDEN / "large.json").read_text())
+    batch = json.loads((GOLDEN / "batch4096.json").read_text())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(enc, w, h, seeds, quality, answers, px):
+        n = len(seeds)
+        cap = 4096 + w * h // 2 if quality <= 50 else 4096 + 2 * w * h
+        outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(n)]
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(n)]
+        stride = (3 * w + 3) & ~3
+        imgs = [jpegamd.Encoder.image(px[s].data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, quality) for s in seeds]
+        enc.encode_batch_async(imgs, [o.data_ptr() for o in outs], cap, [s.data_ptr() for s in sizes], True, stream)
+        enc.finish()
+        for i, seed in enumerate(seeds):
+            e = answers[f"{w}x{h}_seed{seed}_kind0_q{quality}"]
+            got = bytes(outs[i][:int(sizes[i].item())].cpu().numpy())
+            assert (len(got), hashlib.sha256(got).hexdigest()) == (e["size"], e["sha256"]), (w, h, seed, quality, i)
+
+    def pixels(w, h, seeds, answers):
+        px = {}
+        for seed in seeds:
+            bmp = jpegamd.synth_bmp(w, h, seed, 0, 0)
+            assert hashlib.sha256(bmp).hexdigest() == answers[f"{w}x{h}_seed{seed}_kind0_q50"]["bmp_sha256"]
+            px[seed] = upload_pixels(bmp, jpegamd, dev)[1]
+        return px
+
+    enc = jpegamd.Encoder(8192, 8 * 8192)
+    px = pixels(8192, 8192, range(1000, 1016), large)
+    run(enc, 8192, 8192, list(range(1000, 1008)), 50, large, px)
+    run(enc, 8192, 8192, list(range(1008, 1016)), 50, large, px)
+    run(enc, 8192, 8192, list(range(1000, 1008)), 10, large, px)
+    run(enc, 8192, 8192, list(range(1000, 1008)), 90, large, px)
+    del px
+    enc = jpegamd.Encoder(4096, 8 * 4096)
+    px = pixels(4096, 4096, range(2000, 2008), batch)
+    run(enc, 4096, 4096, list(range(2000, 2008)), 50, batch, px)
+
+
+def test_row_stride_of_16_mib_and_more(jpegamd, oracle, dev):
+    """A region of interest inside a very wide buffer: row_stride >= 2^24 does not fit the dword loader's 24-bit multiply and
+    must take the byte loader (64-bit addresses) instead of silently reading wrong rows."""
+    w, h, stride = 200, 24, (1 << 24) + 64
+    bmp = jpegamd.synth_bmp(w, h, 31, 0, 1)                       # top-down, so that stored row r is image row r
+    img, off = jpegamd.parse_bmp(bmp)
+    want = oracle.encode_bmp(bmp)
+    wide = torch.zeros(stride * h, dtype=torch.uint8, device=dev)
+    rows = torch.frombuffer(bytearray(bmp[off:off + img.row_stride * h]), dtype=torch.uint8).to(dev).view(h, img.row_stride)
+    wide.view(h, stride)[:, :img.row_stride] = rows
+    enc = jpegamd.Encoder(w, h)
+    cap = 1 << 20
+    out = torch.empty(cap, dtype=torch.uint8, device=dev); size = torch.zeros(1, dtype=torch.int64, device=dev)
+    d = jpegamd.Encoder.image(wide.data_ptr(), w, h, stride, False, jpegamd.ORDER_BGR, 0)
+    enc.encode_async(d, out.data_ptr(), cap, size.data_ptr(), True, torch.cuda.current_stream().cuda_stream)
+    enc.finish()
+    assert bytes(out[:int(size.item())].cpu().numpy()) == want
+
+
+def test_corrupt_tile_record_ends_in_a_status_code(jpegamd, oracle, dev):
+    """A tile record that claims more bits than 32 blocks can hold (stale or corrupt scratch) must not become a device fault:
+    k_segment_merge trusts a record only up to the worst case, ORs a status bit, and jpegamd_encoder_finish returns
+    JPEGAMD_ERR_RLE_CAPACITY (-6, dsp_port/jpeg_compression/src/jpeg_compression.c:180-181).  The next encode is clean again."""
+    import ctypes as C
+    bmp = jpegamd.synth_bmp(640, 360, 21, 0, 0)
+    want = oracle.encode_bmp(bmp)
+    enc = jpegamd.Encoder(640, 360)
+    got, _ = device_encode(jpegamd, enc, bmp, dev)
+    assert got == want
+    fn = jpegamd.lib.jpegamd_debug_poison_tile_record
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_void_p, C.c_int32, C.c_uint32]
+    for tile, value in ((5, 0xFFFFFFFF), (0, 1 << 20), (134, 32 * 1721 + 1)):      # 640x360: 3 tiles per row, 45 rows
+        assert fn(enc._h, tile, value) == 0
+        with pytest.raises(jpegamd.JpegAmdError) as err:
+            device_encode(jpegamd, enc, bmp, dev, cap=1 << 22)
+        assert err.value.code == -6
+        got, _ = device_encode(jpegamd, enc, bmp, dev)           # the status was cleared; the scratch is simply rewritten
+        assert got == want
+    assert fn(enc._h, 10 ** 6, 0) != 0
 
 
 def test_reference_sample_images(jpegamd, dev):

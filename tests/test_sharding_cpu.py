@@ -125,3 +125,56 @@ def test_two_rank_gloo_batched_gather():
     ret = mgr.dict()
     mp.spawn(_batched_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert ret.get("ok") is True and ret.get("collectives") == 3
+
+
+def _oversize_worker(rank, world, port, ret):
+    """One stream of rank 1 does not fit its slot: settle() has that rank produce it again at the exact size."""
+    for p in (str(PKG / "python"), str(ROOT)):
+        sys.path.insert(0, p)
+    import jpegamd
+    from jpegamd.sharding import BatchedStreamGather
+    from oracle import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slots = 4
+
+    def stream_of(r, s):
+        # record 2 of rank 1 is a 96x64 noise image (a few KB); the others are tiny
+        return oracle.encode_bmp(jpegamd.synth_bmp(96, 64, 5, 1, 0) if (r, s) == (1, 2) else jpegamd.synth_bmp(16 + s, 8, 3 * r + s, 0, 0))
+
+    slot_bytes = (max(len(stream_of(r, s)) for r in range(world) for s in range(slots) if (r, s) != (1, 2)) + 15) // 8 * 8 + 8
+    assert len(stream_of(1, 2)) > slot_bytes
+    g = BatchedStreamGather(slot_bytes, slots, torch.device("cpu"), dst=0, depth=2)
+    for s in range(slots):
+        payload, size = g.record(s)
+        jf = stream_of(rank, s)
+        n = min(len(jf), payload.numel())                 # what an encoder with too small a buffer leaves: a cut stream and the would-be size
+        payload[:n] = torch.frombuffer(bytearray(jf[:n]), dtype=torch.uint8)
+        size[0] = len(jf)
+        g.commit(s)
+    g.wait_all()
+
+    def reencode(step, payload, size):
+        jf = stream_of(rank, step)
+        payload[:len(jf)] = torch.frombuffer(bytearray(jf), dtype=torch.uint8)
+        size[0] = len(jf)
+
+    n_over = g.settle(slots - 1, reencode)
+    if rank == 0:
+        res = g.result(slots - 1)
+        ret["ok"] = all(res[r][s] == stream_of(r, s) for r in range(world) for s in range(slots))
+        ret["n_over"] = n_over
+        ret["collectives"] = g.collectives
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_with_an_oversized_stream():
+    """A record that does not fit its slot no longer fails the buffer (a real configs[3] stream with one dense image):
+    the offenders travel in a second, exact-size gather."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_oversize_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret.get("ok") is True and ret.get("n_over") == 1 and ret.get("collectives") == 2
