@@ -159,7 +159,7 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.edge, segs * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.ffin, segs * 8 * sizeof(uint16_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.grp_bits, (segs / kSegGroup + 2) * sizeof(uint32_t)));
-    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.grp_ff, (segs / kSegGroup + 2) * 8 * sizeof(uint16_t)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.grp_ff, (segs / kSegGroup + 2) * 8 * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->huff, 272 * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->prefix, 512));
     HIP_TRY_CREATE(hipMalloc((void **)&e->stats_dev, sizeof(ScanStats)));

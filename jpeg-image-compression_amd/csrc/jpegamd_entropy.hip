@@ -18,7 +18,7 @@
 
 namespace jpegamd {
 
-constexpr int kWavesE = 4;
+constexpr int kWavesE = 4;               // segments per workgroup = one segment group (SegArrays::grp_bits / grp_ff)
 constexpr int kSegBufWords = 512;               // LDS bit window per wave (typical segment: ~180 words); flushed when nearly full
 constexpr int kPieceWords = 128;                // words of a tile's string moved per step (8 bytes per lane)
 
@@ -250,26 +250,24 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
         s_gmeta[wave][2 + lane] = min(mine, 65535u);
     }
     if (lane == 0) { s_gmeta[wave][0] = seg_bits; s_gmeta[wave][1] = have ? seg_edge : 0u; }   // (no segment: no bits, no ones at either end)
-    // Group aggregate (SegArrays::grp_bits / grp_ff): lane i * 8 + p of wave 0 takes segment i of the group at group phase p.
+    // Group aggregate (SegArrays::grp_bits / grp_ff): lane p < 8 of wave 0 walks the group's segments for group phase p.
     __syncthreads();
     static_assert(kWavesE == kSegGroup, "one workgroup of k_segment_merge = one segment group");
-    if (wave == 0) {
-        const int i = (lane >> 3) & 3, p = lane & 7;
-        uint32_t pre = 0;                           // bits of the group in front of segment i
-#pragma unroll
-        for (int j = 0; j < kWavesE - 1; ++j) pre += (j < i) ? s_gmeta[j][0] : 0u;
-        const uint32_t pi = ((uint32_t)p + pre) & 7u;
-        uint32_t c = s_gmeta[i][2 + pi];
-        if (pi && i > 0) {                          // the byte straddling the start of segment i (fin_owned_ff, jpegamd_finalize.hip)
-            const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(s_gmeta[i - 1][1] & 0x7Fu));
-            const uint32_t lead_ones = (uint32_t)__clz(~((s_gmeta[i][1] >> 8) << 24));
-            c += (tail_ones >= pi && lead_ones >= 8u - pi) ? 1u : 0u;
+    if (wave == 0 && lane < 8) {
+        uint32_t pre = 0, c = 0;                    // bits of the group in front of segment i; owned 0xFF bytes so far
+#pragma unroll 4
+        for (int i = 0; i < kWavesE; ++i) {
+            const uint32_t pi = ((uint32_t)lane + pre) & 7u;
+            c += s_gmeta[i][2 + pi];
+            if (pi && i > 0) {                      // the byte straddling the start of segment i (fin_owned_ff, jpegamd_finalize.hip)
+                const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(s_gmeta[i - 1][1] & 0x7Fu));
+                const uint32_t lead_ones = (uint32_t)__clz(~((s_gmeta[i][1] >> 8) << 24));
+                c += (tail_ones >= pi && lead_ones >= 8u - pi) ? 1u : 0u;
+            }
+            pre += s_gmeta[i][0];
         }
-        if (lane >= 32) c = 0u;
-        c += (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 8) * 4, (int)c);     // i: 0+1, 2+3 (lanes 0..7 and 16..23 matter)
-        c += (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 16) * 4, (int)c);    // lanes 0..7: all four
-        if (lane < 8) a.seg.grp_ff[(size_t)blockIdx.x * 8 + lane] = (uint16_t)min(c, 65535u);
-        if (lane == 0) a.seg.grp_bits[blockIdx.x] = s_gmeta[0][0] + s_gmeta[1][0] + s_gmeta[2][0] + s_gmeta[3][0];
+        a.seg.grp_ff[(size_t)blockIdx.x * 8 + lane] = c;
+        if (lane == 0) a.seg.grp_bits[blockIdx.x] = pre;
     }
 }
 

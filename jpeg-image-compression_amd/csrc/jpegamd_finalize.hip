@@ -61,6 +61,19 @@ __device__ __forceinline__ uint32_t fin_owned_ff(uint4 ffin /*the segment's 8 co
     return c;
 }
 
+// The same for a GROUP's aggregate (eight 32-bit counts; the bytes straddling the group's inner boundaries are in the counts).
+__device__ __forceinline__ uint32_t fin_owned_ff_group(uint4 lo /*phases 0..3*/, uint4 hi /*4..7*/, int t, uint32_t p, uint32_t edge_t, uint32_t edge_prev) {
+    const uint4 h4 = (p & 4u) ? hi : lo;
+    const uint32_t a2 = (p & 2u) ? h4.z : h4.x, b2 = (p & 2u) ? h4.w : h4.y;
+    uint32_t c = (p & 1u) ? b2 : a2;
+    if (p && t > 0) {
+        const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(edge_prev & 0x7Fu));
+        const uint32_t lead_ones = (uint32_t)__clz(~((edge_t >> 8) << 24));
+        c += (tail_ones >= p && lead_ones >= 8u - p) ? 1u : 0u;
+    }
+    return c;
+}
+
 // bit 8k set <=> byte k (little-endian numbering) of w is 0xFF
 __device__ __forceinline__ uint32_t fin_ff_mask(uint32_t w) {
     uint32_t t = w & (w >> 4);
@@ -121,8 +134,8 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     const uint32_t pbits = (have && s > 0) ? a.seg.bits[s - 1] : 0u;
 
     // ---- 1. everything in front of this chunk: bits (64-bit) and owned 0xFF bytes of the segments [0, 16 g) -------------
-    // Thread tid takes four consecutive segments per round of 4096; a block-wide exclusive scan of the bit counts gives
-    // each of them its byte phase (the sum is needed mod 8 only, so 32-bit wrap-around is harmless).
+    // A block-wide exclusive scan of the bit counts gives every entry its byte phase (the sum is needed mod 8 only, so 32-bit
+    // wrap-around is harmless).
 #ifdef JPEGAMD_FIN_SKIP_SCAN       // timing-only build: no scan over the predecessors (wrong offsets, every write still inside the output)
     const int n_before = 0;
 #else
@@ -131,26 +144,34 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     unsigned long long chunk_b0 = 0, chunk_ff0 = 0;
     const bool use_groups = args.use_groups != 0;
     int par = 0;
-    for (int base = 0; base < n_before; base += 4 * 64 * kFinWaves) {
-        const int i = base + 4 * tid;
+    // A thread takes kSegGroup consecutive segments: as ONE entry (k_segment_merge's aggregate of its workgroup) or one by one.
+    // A wave whose entries all lie beyond n_before (half the waves on average) only joins the two barriers and reads the
+    // round's totals.
+    static_assert(kSegGroup == 4, "a thread's four segments are one group of k_segment_merge");
+    const int per_thread = kSegGroup;
+    for (int base = 0; base < n_before; base += per_thread * 64 * kFinWaves) {
+        const int i = base + per_thread * tid;
+        const bool wave_has = base + per_thread * 64 * wave < n_before;
         uint4 b = make_uint4(0u, 0u, 0u, 0u), e = make_uint4(0u, 0u, 0u, 0u), f0 = b, f1 = b, f2 = b, f3 = b;
-        uint32_t eprev = 0;
-        static_assert(kSegGroup == 4, "a thread's four segments are one group of k_entropy");
-        if (i < n_before) {                                      // n_before is a multiple of 16: the four are all in front or none
-            if (use_groups) {                                    // the four as ONE entry: k_entropy's aggregate of its workgroup
-                b.x = a.seg.grp_bits[i / kSegGroup];
-                f0 = *reinterpret_cast<const uint4 *>(a.seg.grp_ff + (size_t)(i / kSegGroup) * 8);
-                e.x = a.seg.edge[i];
-            } else {
-                b = *reinterpret_cast<const uint4 *>(a.seg.bits + i);
-                e = *reinterpret_cast<const uint4 *>(a.seg.edge + i);
-                const uint4 *fp = reinterpret_cast<const uint4 *>(a.seg.ffin + (size_t)i * 8);
-                f0 = fp[0]; f1 = fp[1]; f2 = fp[2]; f3 = fp[3];
+        uint32_t eprev = 0, tot = 0, incl = 0;
+        if (wave_has) {
+            if (i < n_before) {                                  // n_before is a multiple of 16: a thread's segments are all in front or none
+                if (use_groups) {
+                    b.x = a.seg.grp_bits[i / kSegGroup];
+                    f0 = *reinterpret_cast<const uint4 *>(a.seg.grp_ff + (size_t)(i / kSegGroup) * 8);
+                    f1 = *reinterpret_cast<const uint4 *>(a.seg.grp_ff + (size_t)(i / kSegGroup) * 8 + 4);
+                    e.x = a.seg.edge[i];
+                } else {
+                    b = *reinterpret_cast<const uint4 *>(a.seg.bits + i);
+                    e = *reinterpret_cast<const uint4 *>(a.seg.edge + i);
+                    const uint4 *fp = reinterpret_cast<const uint4 *>(a.seg.ffin + (size_t)i * 8);
+                    f0 = fp[0]; f1 = fp[1]; f2 = fp[2]; f3 = fp[3];
+                }
+                if (i > 0) eprev = a.seg.edge[i - 1];
             }
-            if (i > 0) eprev = a.seg.edge[i - 1];
+            tot = b.x + b.y + b.z + b.w;
+            incl = wave_incl_scan_u32(tot);
         }
-        const uint32_t tot = b.x + b.y + b.z + b.w;
-        const uint32_t incl = wave_incl_scan_u32(tot);
         uint32_t *wb = s_wbits[par], *wf = s_wff[par];            // double-buffered by round: no barrier before the next round's writes
         if (lane == 63) wb[wave] = incl;
         __syncthreads();
@@ -158,16 +179,20 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
         const uint32_t wt = lane < kFinWaves ? wb[lane] : 0u;
         const uint32_t wincl = half_incl_scan_dpp(wt);            // kFinWaves == 16: one DPP row
         const uint32_t round_bits = (uint32_t)__builtin_amdgcn_readlane((int)wincl, kFinWaves - 1);
-        const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wave);
-        const uint32_t x0 = (uint32_t)chunk_b0 + woff + incl - tot;                 // bit offset of segment i, mod 2^32
-        uint32_t ff = 0;
-        if (i < n_before) {
-            ff = fin_owned_ff(f0, i, x0 & 7u, e.x, eprev);       // (a group's counts hold the bytes straddling its inner boundaries)
-            if (!use_groups)
-                ff += fin_owned_ff(f1, i + 1, (x0 + b.x) & 7u, e.y, e.x) + fin_owned_ff(f2, i + 2, (x0 + b.x + b.y) & 7u, e.z, e.y) +
-                      fin_owned_ff(f3, i + 3, (x0 + b.x + b.y + b.z) & 7u, e.w, e.z);
+        uint32_t wff = 0;
+        if (wave_has) {
+            const uint32_t woff = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wave);
+            const uint32_t x0 = (uint32_t)chunk_b0 + woff + incl - tot;             // bit offset of segment i, mod 2^32
+            uint32_t ff = 0;
+            if (i < n_before) {
+                if (use_groups)
+                    ff = fin_owned_ff_group(f0, f1, i, x0 & 7u, e.x, eprev);
+                else
+                    ff = fin_owned_ff(f0, i, x0 & 7u, e.x, eprev) + fin_owned_ff(f1, i + 1, (x0 + b.x) & 7u, e.y, e.x) + fin_owned_ff(f2, i + 2, (x0 + b.x + b.y) & 7u, e.z, e.y) +
+                          fin_owned_ff(f3, i + 3, (x0 + b.x + b.y + b.z) & 7u, e.w, e.z);
+            }
+            wff = (uint32_t)wave_sum_i32((int)ff);
         }
-        const uint32_t wff = (uint32_t)wave_sum_i32((int)ff);
         if (lane == 0) wf[wave] = wff;
         __syncthreads();
         const uint32_t ft = lane < kFinWaves ? wf[lane] : 0u;

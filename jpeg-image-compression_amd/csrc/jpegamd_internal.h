@@ -112,13 +112,13 @@ struct SegArrays {
     uint32_t *exact;            // [num_segs] coefficients recomputed in exact order
     uint32_t *edge;             // [num_segs] (first 8 bits << 8) | last 7 bits: what the byte straddling two segments is made of
     uint16_t *ffin;             // [num_segs][8] 0xFF bytes lying wholly inside the segment when its first bit sits at byte phase p
-    // Per GROUP of kSegGroup consecutive segments (one workgroup of k_entropy), so that k_finalize's scan over everything in
+    // Per GROUP of kSegGroup consecutive segments (one workgroup of k_segment_merge), so that k_finalize's scan over everything in
     // front of a chunk reads a quarter of the entries: the group's bits, and the 0xFF bytes its segments own when the group's
     // first bit sits at byte phase p -- without the byte straddling the group's start (that needs the segment in front).
     uint32_t *grp_bits;         // [ceil(num_segs / kSegGroup)]
-    uint16_t *grp_ff;           // [ceil(num_segs / kSegGroup)][8]
+    uint32_t *grp_ff;           // [ceil(num_segs / kSegGroup)][8] (32-bit: sixteen worst-case segments hold more than 65535 bytes)
 };
-constexpr int kSegGroup = 4;
+constexpr int kSegGroup = 4;      // (16 -- one k_finalize chunk -- was measured: k_segment_merge's 1024-thread workgroups cost it 60 %)
 
 struct TransformOutM {
     const MfmaTables *tables;   // device copy

@@ -235,23 +235,31 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
 #endif
 
-    {
-        const int t = (int)threadIdx.x;
-        const uint4 *src = reinterpret_cast<const uint4 *>(out.tables->afrag);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_afrag);
-        for (int i = t; i < kAFragWords / 4; i += 64 * kWavesT) dst[i] = src[i];
-        const uint4 *csrc = reinterpret_cast<const uint4 *>(out.code_tab);
-        for (int i = t; i < kCodeWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(s_code)[i] = csrc[i];
-        for (int i = t; i < kWavesT * kWinWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(&s_win[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (t < 64) {
-            s_qt[2 * t] = out.tables->qmul[t]; s_qt[2 * t + 1] = out.tables->qthr[t];
-            s_qstep[t] = out.tables->qstep[t];
-            s_cos[t] = kCosFM[t];
-            s_zz[t] = kZZ[t];
-            if (t < 8) { s_qt[128 + 16 * (t & 1) + (t >> 1)] = out.tables->grp_thr[t]; s_qt[132 + 16 * (t & 1) + (t >> 1)] = out.tables->flag_thr[t]; }
-        }
-    }
-    __syncthreads();
+#ifndef JPEGAMD_PROLOGUE_ROWS_FIRST
+#define JPEGAMD_PROLOGUE_ROWS_FIRST 1      // the first tile's pixel rows are requested AHEAD of the workgroup's tables: the two HBM latencies overlap
+#endif
+#define JPEGAMD_LOAD_TABLES() \
+        { \
+            const int t = (int)threadIdx.x; \
+            const uint4 *src = reinterpret_cast<const uint4 *>(out.tables->afrag); \
+            uint4 *dst = reinterpret_cast<uint4 *>(s_afrag); \
+            for (int i = t; i < kAFragWords / 4; i += 64 * kWavesT) dst[i] = src[i]; \
+            const uint4 *csrc = reinterpret_cast<const uint4 *>(out.code_tab); \
+            for (int i = t; i < kCodeWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(s_code)[i] = csrc[i]; \
+            for (int i = t; i < kWavesT * kWinWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(&s_win[0][0])[i] = make_uint4(0u, 0u, 0u, 0u); \
+            if (t < 64) { \
+                s_qt[2 * t] = out.tables->qmul[t]; s_qt[2 * t + 1] = out.tables->qthr[t]; \
+                s_qstep[t] = out.tables->qstep[t]; \
+                s_cos[t] = kCosFM[t]; \
+                s_zz[t] = kZZ[t]; \
+                if (t < 8) { s_qt[128 + 16 * (t & 1) + (t >> 1)] = out.tables->grp_thr[t]; s_qt[132 + 16 * (t & 1) + (t >> 1)] = out.tables->flag_thr[t]; } \
+            } \
+        } \
+        __syncthreads(); \
+
+#if !JPEGAMD_PROLOGUE_ROWS_FIRST
+    JPEGAMD_LOAD_TABLES()
+#endif
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
@@ -343,6 +351,10 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     int tile = first < cur_hi ? to_tile(first) : im.tile_begin;     // picture tile of the iteration (carried: to_tile() once per tile)
     TileGeo tg = geo(tile);
     if (first < cur_hi && tg.interior) request_rows(tg, raw);
+#if JPEGAMD_PROLOGUE_ROWS_FIRST
+    JPEGAMD_LOAD_TABLES()
+#endif
+#undef JPEGAMD_LOAD_TABLES
 #ifdef JPEGAMD_STAMPS
     unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_last)::"memory");
@@ -377,8 +389,9 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         {
         uint32_t sl;                           // (an opaque lane id: the stash addresses are not worth four registers across the whole loop)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl));
+        uint32_t *const sp0 = &s_pix[wave][(sl >> 5) * 132 + (sl & 31) * 4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&s_pix[wave][(2 * s + (sl >> 5)) * 132 + (sl & 31) * 4]) = bfrag[s];
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&sp0[2 * s * 132]) = bfrag[s];     // (one address, four immediate offsets)
         }
 #endif
 #if JPEGAMD_TICKET_AT == 1
@@ -432,8 +445,9 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         {
         uint32_t sl;                           // (an opaque lane id: the stash addresses are not worth four registers across the whole loop)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl));
+        uint32_t *const sp0 = &s_pix[wave][(sl >> 5) * 132 + (sl & 31) * 4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&s_pix[wave][(2 * s + (sl >> 5)) * 132 + (sl & 31) * 4]) = bfrag[s];
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&sp0[2 * s * 132]) = bfrag[s];     // (one address, four immediate offsets)
         }
 #endif
         TSTAMP(2);
