@@ -31,6 +31,7 @@ using namespace jpegamd;
 struct JpegAmdEncoder {
     int device = -1;
     int max_w = 0, max_h = 0, max_segs = 0, max_tiles = 0;
+    size_t words_cap = 0;               // words of seg.words
     // device scratch, sized once for max_w x max_h
     SegArrays seg = {};
     uint32_t *huff = nullptr;
@@ -61,9 +62,9 @@ struct JpegAmdEncoder {
     bool timed = false;
 };
 
-static int segs_for(int w, int h, int *bw, int *bh, int *spr) {
+static int segs_for(int w, int h, int *bw, int *bh, int *spr, int seg_tiles = kSegTiles) {
     const int blocks_w = (w + 7) / 8, blocks_h = (h + 7) / 8;
-    const int per_row = (blocks_w + kSegBlocks - 1) / kSegBlocks;
+    const int per_row = (blocks_w + kTileBlocks * seg_tiles - 1) / (kTileBlocks * seg_tiles);
     if (bw) *bw = blocks_w;
     if (bh) *bh = blocks_h;
     if (spr) *spr = per_row;
@@ -152,7 +153,14 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     e->max_segs = segs_for(max_width, max_height, nullptr, nullptr, nullptr);
     e->max_tiles = ((max_height + 7) / 8) * (((max_width + 7) / 8 + kTileBlocks - 1) / kTileBlocks);
     const size_t segs = (size_t)e->max_segs + 16;                 // k_finalize reads the per-segment arrays four at a time
-    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.words, (size_t)e->max_segs * kSegCapWords * sizeof(uint32_t)));
+    // (room for either segment length: the same blocks as fewer, longer segments need a little more than as many short ones)
+    {
+        const size_t w8 = (size_t)e->max_segs * kSegCapWords;
+        const size_t w16 = (size_t)segs_for(max_width, max_height, nullptr, nullptr, nullptr, kSegTilesBatch) * seg_cap_words(kSegTilesBatch);
+        e->words_cap = (w8 > w16 ? w8 : w16) + seg_cap_words(kSegTilesBatch);
+    }
+    HIP_TRY_CREATE(hipMalloc((void **)&e->seg.words, e->words_cap * sizeof(uint32_t)));
+    e->seg.words_stride = kSegCapWords;
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.bits, segs * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.syms, segs * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->seg.exact, segs * sizeof(uint32_t)));
@@ -256,7 +264,7 @@ static bool context_fits(const JpegAmdEncoder *e, int w, int h) {
     return segs_for(w, h, nullptr, nullptr, nullptr) <= e->max_segs && tiles <= e->max_tiles;
 }
 
-static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageDesc *d) {
+static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageDesc *d, int seg_tiles = kSegTiles) {
     if (!img || !img->pixels || img->width <= 0 || img->height <= 0 || img->width > 65535 || img->height > 65535)
         return JPEGAMD_ERR_ARG;
     if (img->row_stride < 3 * img->width) return JPEGAMD_ERR_ARG;
@@ -267,7 +275,8 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     // Y = (77 R + 150 G + 29 B) >> 8 (natural_c/src/core/converter.c:51); weights follow the STORED byte order.
     d->weights = img->channel_order == JPEGAMD_ORDER_BGR ? (29u | (150u << 8) | (77u << 16))
                                                          : (77u | (150u << 8) | (29u << 16));
-    d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row);
+    d->seg_tiles = seg_tiles;
+    d->num_segs = segs_for(img->width, img->height, &d->blocks_w, &d->blocks_h, &d->segs_per_row, seg_tiles);
     d->tiles_per_row = (d->blocks_w + kTileBlocks - 1) / kTileBlocks;
     d->num_tiles = d->tiles_per_row * d->blocks_h;
     d->tile_begin = 0; d->tile_end = d->num_tiles;
@@ -307,6 +316,8 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     std::memset(&ea, 0, sizeof(ea));
     ea.tile_head = e->tile_head; ea.tile_over = e->tile_over;
     ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
+    ea.seg_tiles = im.seg_tiles;
+    e->seg.words_stride = (uint32_t)seg_cap_words(im.seg_tiles);
     ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
     ea.tiles_per_image = im.batch > 1 ? im.num_tiles : 0;
     ea.seg = e->seg;
@@ -387,6 +398,7 @@ static int32_t exchange_args(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t
     if (rc) return rc;
     if (!dense || !meta) return JPEGAMD_ERR_ARG;
     std::memset(x, 0, sizeof(*x));
+    e->seg.words_stride = (uint32_t)kSegCapWords;          // (the sharded path uses the standard segment length)
     x->seg = e->seg;
     x->s0 = by0 * im.segs_per_row; x->s1 = by1 * im.segs_per_row;
     x->dense = dense; x->dense_cap_words = cap; x->meta = meta; x->total_words = total;
@@ -426,6 +438,7 @@ extern "C" int32_t jpegamd_finalize_async(JpegAmdEncoder *e, const JpegAmdImage 
     rc = prepare_constants(e, img, with_container != 0);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
+    e->seg.words_stride = (uint32_t)kSegCapWords;
     if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
     e->last_stream = stream;
@@ -469,8 +482,14 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
                                               void *stream_) {
     if (!e || !imgs || !outs_dev || !out_sizes_dev || count < 1 || count > kMaxBatch) return JPEGAMD_ERR_ARG;
     ImageDesc im;
-    int32_t rc = describe(e, &imgs[0], &im);
+    int seg_tiles = count >= 4 ? kSegTilesBatch : kSegTiles;             // many pictures: longer segments (jpegamd_internal.h)
+    int32_t rc = describe(e, &imgs[0], &im, seg_tiles);
     if (rc) return rc;
+    if (seg_tiles != kSegTiles && (size_t)count * im.num_segs * seg_cap_words(seg_tiles) > e->words_cap) {   // (a geometry other than the context's own)
+        seg_tiles = kSegTiles;
+        rc = describe(e, &imgs[0], &im, seg_tiles);
+        if (rc) return rc;
+    }
     for (int i = 0; i < count; ++i) {
         const JpegAmdImage &g = imgs[i];
         if (!outs_dev[i] || !out_sizes_dev[i] || !g.pixels) return JPEGAMD_ERR_ARG;
@@ -480,7 +499,8 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
         im.batch_pixels[i] = (const uint8_t *)g.pixels;
         if ((((uintptr_t)g.pixels) & 3u) != 0) im.fast_ok = 0;
     }
-    if ((int64_t)count * im.num_tiles > e->max_tiles || (int64_t)count * im.num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
+    if ((int64_t)count * im.num_tiles > e->max_tiles || (int64_t)count * im.num_segs > e->max_segs ||
+        (size_t)count * im.num_segs * seg_cap_words(seg_tiles) > e->words_cap) return JPEGAMD_ERR_TOO_LARGE;
     im.batch = count;
     im.tile_end = count * im.num_tiles;
     im.seg_end = count * im.num_segs;

@@ -19,7 +19,7 @@
 namespace jpegamd {
 
 constexpr int kWavesE = 4;               // segments per workgroup = one segment group (SegArrays::grp_bits / grp_ff)
-constexpr int kSegBufWords = 512;               // LDS bit window per wave (typical segment: ~180 words); flushed when nearly full
+constexpr int kSegBufWords = 512;               // LDS bit window per wave and 8 tiles (typical segment: ~180 words); flushed when nearly full
 constexpr int kPieceWords = 128;                // words of a tile's string moved per step (8 bytes per lane)
 
 // 0xFF bytes wholly inside the bit string, by byte phase: for the word `cur` followed by `nxt` (MSB-first), bit (31 - o) of
@@ -31,9 +31,13 @@ __device__ __forceinline__ uint32_t ones8_starts(uint32_t cur, uint32_t nxt) {
     return hi;
 }
 
+template <int kTiles>
 __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs a) {
+    constexpr int kBuf = kSegBufWords * kTiles / 8;               // LDS bit window per wave: a typical segment is ~23 words per tile
+    constexpr int kLanesPerTile = 64 / kTiles;                    // lanes that share a tile's string in the lane-parallel placement
+    constexpr int kStepWords = kLanesPerTile * 4;                 // words of every tile's string moved per step
     __shared__ uint32_t s_dc[16];                   // DC table by size: (length << 16) | code
-    __shared__ uint32_t s_win[kWavesE][kSegBufWords + 8];
+    __shared__ uint32_t s_win[kWavesE][kBuf + 8];
     __shared__ uint32_t s_gmeta[kWavesE][12];       // {bits, edge, ff[8]} of the workgroup's segments, for the group aggregate
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int seg = a.seg_begin + (int)blockIdx.x * kWavesE + wave;
@@ -47,8 +51,8 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
     const int image = a.tiles_per_image ? segc / a.num_segs : 0;    // a batch: every image has num_segs segments and tiles_per_image tiles
     const int sl = segc - image * a.num_segs;
     const int by = sl / a.segs_per_row;
-    const int tx0 = (sl - by * a.segs_per_row) * kSegTiles;
-    const int ntiles = have ? min(kSegTiles, a.tiles_per_row - tx0) : 0;
+    const int tx0 = (sl - by * a.segs_per_row) * kTiles;
+    const int ntiles = have ? min(kTiles, a.tiles_per_row - tx0) : 0;
     const int tile_in_image = by * a.tiles_per_row + tx0;
     const int tile0 = image * a.tiles_per_image + tile_in_image;
 
@@ -71,17 +75,18 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
         const_cast<uint32_t *>(tbase), 0, ntiles * kTileHeadWords * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint32_t *>(a.tile_over + (size_t)tile0 * kTileOverCap), 0, ntiles * kTileOverCap * 4, 0x00020000);
-    // The strings, lane-parallel over the segment's tiles: lane (t = l >> 3, i = l & 7) takes words 32 k + 4 i .. + 3 of tile t's
-    // string in step k.  The first two steps (64 words: all of a photo-like tile) are requested before anything is known.
-    const uint32_t lt = (uint32_t)lane >> 3, li4 = ((uint32_t)lane & 7u) * 4u;
+    // The strings, lane-parallel over the segment's tiles: with 8 tiles lane (t = l >> 3, i = l & 7) takes words 32 k + 4 i .. + 3
+    // of tile t's string in step k (with 16 tiles: t = l >> 2, words 16 k + 4 i ..).  The first two steps (64 / 32 words: all or
+    // most of a photo-like tile) are requested before anything is known.
+    const uint32_t lt = (uint32_t)lane / (uint32_t)kLanesPerTile, li4 = ((uint32_t)lane % (uint32_t)kLanesPerTile) * 4u;
     const int head_off = (int)((lt * (uint32_t)kTileHeadWords + (uint32_t)kTileRecWords + li4) * 4u);
     u32x4 quad[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) quad[k] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, head_off + k * 128, 0, 0);
+    for (int k = 0; k < 2; ++k) quad[k] = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, head_off + k * kStepWords * 4, 0, 0);
 
 #pragma unroll
-    for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
-    if (lane < 8) win[kSegBufWords + lane] = 0u;
+    for (int i = 0; i < kBuf / 64; ++i) win[i * 64 + lane] = 0u;
+    if (lane < 8) win[kBuf + lane] = 0u;
     if (threadIdx.x < 16) s_dc[threadIdx.x] = dcword;
     __syncthreads();
 
@@ -131,10 +136,10 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
             }
         }
     };
-    uint32_t *const segw = a.seg.words + (size_t)seg * kSegCapWords;
+    uint32_t *const segw = a.seg.words + (size_t)seg * a.seg.words_stride;
     // Everything below bit `upto` of the segment is final: write the complete words out when the next piece might not fit.
     const auto make_room = [&](uint32_t upto /*bits*/, uint32_t need_end /*bit behind the next piece*/) {
-        if (__builtin_expect((need_end >> 5) - wbase + 3u > (uint32_t)kSegBufWords, 0)) {
+        if (__builtin_expect((need_end >> 5) - wbase + 3u > (uint32_t)kBuf, 0)) {
             const uint32_t done = (upto >> 5) - wbase;                    // complete words in the window
             if (done) {
                 census(done - 1u, flushed);                                // the last complete word waits for its successor
@@ -143,8 +148,8 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
                 if (!flushed) first_word = win[0];
                 last_word = win[done - 1];
 #pragma unroll
-                for (int i = 0; i < kSegBufWords / 64; ++i) win[i * 64 + lane] = 0u;
-                if (lane < 8) win[kSegBufWords + lane] = 0u;
+                for (int i = 0; i < kBuf / 64; ++i) win[i * 64 + lane] = 0u;
+                if (lane < 8) win[kBuf + lane] = 0u;
                 if (lane == 0) win[0] = part;
                 wbase += done;
                 flushed = true;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
 
     const uint32_t nwords_t = (rbits + 31u) >> 5;                                 // lane t < 8: words of tile t's string
     const uint32_t max_words = (uint32_t)wave_max_u32(nwords_t);
-    if (__builtin_expect(seg_bits <= (uint32_t)((kSegBufWords - 8) * 32) && max_words <= (uint32_t)kTileHeadStr, 1)) {
+    if (__builtin_expect(seg_bits <= (uint32_t)((kBuf - 8) * 32) && max_words <= (uint32_t)kTileHeadStr, 1)) {
         // The whole segment fits the window and every string its tile's head (nearly always): all tiles at once.
         const uint32_t my_start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lt * 4u), (int)(toff + dclen));   // bit offset of my tile's string
         const uint32_t my_words = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lt * 4u), (int)nwords_t);
@@ -164,10 +169,10 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
             atomicOr(&win[wi], (uint32_t)(s64 >> 32));
             atomicOr(&win[wi + 1], (uint32_t)s64);
         }
-        for (uint32_t k = 0; k * 32u < max_words; ++k) {
+        for (uint32_t k = 0; k * (uint32_t)kStepWords < max_words; ++k) {
             u32x4 q = k == 0 ? quad[0] : quad[1];
-            if (k >= 2) q = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, head_off + (int)k * 128, 0, 0);
-            const uint32_t j0 = k * 32u + li4;                        // my first word of this step
+            if (k >= 2) q = __builtin_amdgcn_raw_buffer_load_b128(hrsrc, head_off + (int)k * kStepWords * 4, 0, 0);
+            const uint32_t j0 = k * (uint32_t)kStepWords + li4;       // my first word of this step
             if (j0 < my_words) {
                 // words beyond the string are not zero in memory: mask by count
                 const uint32_t x0 = q[0], x1 = j0 + 1u < my_words ? q[1] : 0u, x2 = j0 + 2u < my_words ? q[2] : 0u, x3 = j0 + 3u < my_words ? q[3] : 0u;
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
         // a time: lane l holds words 2 l and 2 l + 1 of the piece; shifted by the piece's bit offset they land in three window
         // words, the outer two shared with the neighbour lanes (ds_or).
     #pragma unroll
-        for (int t = 0; t < kSegTiles; ++t) {
+        for (int t = 0; t < kTiles; ++t) {
             if (t >= ntiles) break;
             const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)toff, t);
             const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)dclen, t);
@@ -247,35 +252,42 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
     }
     if (lane < 8) {
         if (have) a.seg.ffin[(size_t)seg * 8 + lane] = (uint16_t)min(mine, 65535u);
-        s_gmeta[wave][2 + lane] = min(mine, 65535u);
+        s_gmeta[wave][2 + lane] = mine;
     }
     if (lane == 0) { s_gmeta[wave][0] = seg_bits; s_gmeta[wave][1] = have ? seg_edge : 0u; }   // (no segment: no bits, no ones at either end)
-    // Group aggregate (SegArrays::grp_bits / grp_ff): lane p < 8 of wave 0 walks the group's segments for group phase p.
+    // Group aggregate (SegArrays::grp_bits / grp_ff): lane i * 8 + p of wave 0 takes segment i of the group at group phase p.
     __syncthreads();
-    static_assert(kWavesE == kSegGroup, "one workgroup of k_segment_merge = one segment group");
-    if (wave == 0 && lane < 8) {
-        uint32_t pre = 0, c = 0;                    // bits of the group in front of segment i; owned 0xFF bytes so far
-#pragma unroll 4
-        for (int i = 0; i < kWavesE; ++i) {
-            const uint32_t pi = ((uint32_t)lane + pre) & 7u;
-            c += s_gmeta[i][2 + pi];
-            if (pi && i > 0) {                      // the byte straddling the start of segment i (fin_owned_ff, jpegamd_finalize.hip)
-                const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(s_gmeta[i - 1][1] & 0x7Fu));
-                const uint32_t lead_ones = (uint32_t)__clz(~((s_gmeta[i][1] >> 8) << 24));
-                c += (tail_ones >= pi && lead_ones >= 8u - pi) ? 1u : 0u;
-            }
-            pre += s_gmeta[i][0];
+    static_assert(kWavesE == kSegGroup && kWavesE == 4, "one workgroup of k_segment_merge = one segment group of four");
+    if (wave == 0) {
+        const int i = (lane >> 3) & 3, p = lane & 7;
+        uint32_t pre = 0;                           // bits of the group in front of segment i
+#pragma unroll
+        for (int j = 0; j < kWavesE - 1; ++j) pre += (j < i) ? s_gmeta[j][0] : 0u;
+        const uint32_t pi = ((uint32_t)p + pre) & 7u;
+        uint32_t c = s_gmeta[i][2 + pi];
+        if (pi && i > 0) {                          // the byte straddling the start of segment i (fin_owned_ff, jpegamd_finalize.hip)
+            const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(s_gmeta[i - 1][1] & 0x7Fu));
+            const uint32_t lead_ones = (uint32_t)__clz(~((s_gmeta[i][1] >> 8) << 24));
+            c += (tail_ones >= pi && lead_ones >= 8u - pi) ? 1u : 0u;
         }
-        a.seg.grp_ff[(size_t)blockIdx.x * 8 + lane] = c;
-        if (lane == 0) a.seg.grp_bits[blockIdx.x] = pre;
+        if (lane >= 32) c = 0u;
+        c += (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 8) * 4, (int)c);     // i: 0+1, 2+3 (lanes 0..7 and 16..23 matter)
+        c += (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 16) * 4, (int)c);    // lanes 0..7: all four
+        if (lane < 8) a.seg.grp_ff[(size_t)blockIdx.x * 8 + lane] = c;
+        if (lane == 0) a.seg.grp_bits[blockIdx.x] = s_gmeta[0][0] + s_gmeta[1][0] + s_gmeta[2][0] + s_gmeta[3][0];
     }
 }
 
 int launch_segment_merge(const MergeArgs &a, void *stream, void *const *ev) {
     if (a.seg_end <= a.seg_begin) return 0;
     const dim3 grid((a.seg_end - a.seg_begin + kWavesE - 1) / kWavesE), block(64 * kWavesE);
-    if (ev) hipExtLaunchKernelGGL(k_segment_merge, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
-    else hipLaunchKernelGGL(k_segment_merge, grid, block, 0, (hipStream_t)stream, a);
+    if (a.seg_tiles == kSegTilesBatch) {
+        if (ev) hipExtLaunchKernelGGL(k_segment_merge<kSegTilesBatch>, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
+        else hipLaunchKernelGGL(k_segment_merge<kSegTilesBatch>, grid, block, 0, (hipStream_t)stream, a);
+    } else {
+        if (ev) hipExtLaunchKernelGGL(k_segment_merge<kSegTiles>, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
+        else hipLaunchKernelGGL(k_segment_merge<kSegTiles>, grid, block, 0, (hipStream_t)stream, a);
+    }
     return (int)hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t fin_tail_bits(const View &a, int s, int need
         const uint32_t tp = a.seg.bits[sp];
         const int take = min(need - got, (int)tp);
         if (take > 0) {
-            val |= fin_bits_at(a.seg.words + (size_t)sp * kSegCapWords, tp - (uint32_t)take, take) << got;
+            val |= fin_bits_at(a.seg.words + (size_t)sp * a.seg.words_stride, tp - (uint32_t)take, take) << got;
             got += take;
         }
     }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     FinalizeView a;
     {
         const size_t s0 = (size_t)image * (size_t)args.num_segs;
-        a.seg.words = args.seg.words + s0 * kSegCapWords;
+        a.seg.words = args.seg.words + s0 * args.seg.words_stride; a.seg.words_stride = args.seg.words_stride;
         a.seg.bits = args.seg.bits + s0; a.seg.syms = args.seg.syms + s0; a.seg.exact = args.seg.exact + s0;
         a.seg.edge = args.seg.edge + s0; a.seg.ffin = args.seg.ffin + s0 * 8;
         a.seg.grp_bits = args.seg.grp_bits + s0 / kSegGroup; a.seg.grp_ff = args.seg.grp_ff + (s0 / kSegGroup) * 8;   // (use_groups: s0 is a multiple)
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     const uint32_t ff_in = (uint32_t)__builtin_amdgcn_readlane((int)(iff - vf), wave);
     const uint32_t prev_edge = (uint32_t)__builtin_amdgcn_readlane((int)ve_prev, wave);
 
-    const uint32_t *words = a.seg.words + (size_t)s * kSegCapWords;
+    const uint32_t *words = a.seg.words + (size_t)s * a.seg.words_stride;
     const unsigned long long b0 = chunk_b0 + (uint32_t)__builtin_amdgcn_readlane((int)off_in, wave);
     const unsigned long long b1 = b0 + my_bits;
     const uint32_t nown = (uint32_t)((b1 >> 3) - (b0 >> 3));                       // bytes whose last bit lies in this segment
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_seg_copy(const SegExchange x) {
     if (i >= x.s1 - x.s0) return;
     const uint32_t *m = x.meta + (size_t)i * kSegMetaWords;
     const uint32_t bits = m[0], off = m[1], nw = (bits + 31u) >> 5;
-    uint32_t *strided = x.seg.words + (size_t)(x.s0 + i) * kSegCapWords;
+    uint32_t *strided = x.seg.words + (size_t)(x.s0 + i) * x.seg.words_stride;
     if (kExport) {
         if ((uint64_t)off + nw > x.dense_cap_words) return;           // flagged by k_seg_offsets
         for (uint32_t j = (uint32_t)lane; j < nw; j += 64) x.dense[off + j] = strided[j];

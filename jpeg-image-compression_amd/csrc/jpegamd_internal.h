@@ -20,9 +20,15 @@ constexpr int kTileBlocks = 32;
 #endif
 constexpr int kSegTiles = JPEGAMD_SEG_TILES;
 constexpr int kSegBlocks = kTileBlocks * kSegTiles;                  // 256
+// A launch that codes four or more pictures (jpegamd_encode_batch_async) has waves to spare and uses segments of 16 tiles:
+// the per-segment costs of k_segment_merge and k_finalize -- both mostly per-segment bookkeeping -- are paid half as often.
+// (A single picture keeps 8: with 16 its two small kernels have too few waves: measured +20 % each.)
+constexpr int kSegTilesBatch = 16;
+constexpr int kSegTilesMax = kSegTilesBatch;
 // Worst case bits per block: DC 9+11, 63 x (16+11) AC (quality 100 -> 11-bit amplitudes).
 constexpr int kMaxBlockBits = 20 + 63 * 27;                          // 1721
-constexpr int kSegCapWords = ((kSegBlocks * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64;   // words reserved per segment
+constexpr int seg_cap_words(int seg_tiles) { return ((kTileBlocks * seg_tiles * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64; }   // words reserved per segment
+constexpr int kSegCapWords = seg_cap_words(kSegTiles);
 constexpr int kAFragWords = 2 * 2 * 4 * 64 * 4;                      // [term][chain][kstep][lane] x 8 binary16 = 16 KiB
 constexpr float kMfmaScale = 2048.0f;                                // the accumulator chains hold kMfmaScale * LUT sum (hi chain + lo chain)
 
@@ -98,6 +104,7 @@ struct ImageDesc {
     int32_t width, height, row_stride, bottom_up;
     uint32_t weights;          // luma weights for stored bytes 0,1,2 (byte 3 = 0)
     int32_t blocks_w, blocks_h, segs_per_row, num_segs;
+    int32_t seg_tiles;                  // tiles per segment of this launch: kSegTiles, or kSegTilesBatch
     int32_t tiles_per_row, num_tiles;
     int32_t tile_begin, tile_end;       // tiles this launch transforms (whole images: 0, batch * num_tiles; a block-row shard otherwise)
     int32_t seg_begin, seg_end;         // segments this launch codes (whole images: 0, batch * num_segs)
@@ -106,7 +113,8 @@ struct ImageDesc {
 
 // What k_entropy leaves per segment (and what one image sharded over GPUs exchanges, besides the bit strings).
 struct SegArrays {
-    uint32_t *words;            // [num_segs][kSegCapWords] MSB-first bit string, unstuffed
+    uint32_t *words;            // [num_segs][words_stride] MSB-first bit string, unstuffed
+    uint32_t words_stride;      // seg_cap_words(tiles per segment of the launch)
     uint32_t *bits;             // [num_segs] bit count
     uint32_t *syms;             // [num_segs] run/size symbols coded (DTO rle_count)
     uint32_t *exact;            // [num_segs] coefficients recomputed in exact order
@@ -140,6 +148,7 @@ struct MergeArgs {              // k_segment_merge: the tile strings of a segmen
     const uint32_t *tile_head, *tile_over;
     const uint32_t *huff;           // [272] (len << 16) | code: AC by run/size symbol, then 16 DC sizes
     int32_t num_segs, segs_per_row, tiles_per_row;     // per image
+    int32_t seg_tiles;              // tiles per segment: kSegTiles or kSegTilesBatch
     int32_t seg_begin, seg_end;     // segments this launch codes (whole images: 0, batch * num_segs)
     int32_t tiles_per_image;        // a batch: segment s belongs to image s / num_segs, whose tiles start at image * tiles_per_image
     SegArrays seg;

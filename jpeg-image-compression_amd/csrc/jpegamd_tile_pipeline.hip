@@ -126,8 +126,8 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 #ifndef JPEGAMD_THIRD_ALWAYS
 #define JPEGAMD_THIRD_ALWAYS 1
 #endif
-#ifndef JPEGAMD_PREPAD
-#define JPEGAMD_PREPAD 1
+#ifndef JPEGAMD_SHORT_TAIL
+#define JPEGAMD_SHORT_TAIL 1          // a list's last 64 items or fewer are coded one per lane (half the work of a two-per-lane pass)
 #endif
 #ifndef JPEGAMD_TILE_GROUPS
 #define JPEGAMD_TILE_GROUPS 64
@@ -674,7 +674,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             //  operation -- in the middle of the phases that are supposed to hide the next tile's row loads)
             uint32_t cl;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(cl));
-#if JPEGAMD_PREPAD
             {   // the list is padded to whole passes with padding items (no bits): the coder then needs no tail masks
                 uint32_t padv = kItPadValue;
                 asm volatile("" : "+v"(padv));                 // (not a register held across the whole tile loop)
@@ -682,24 +681,53 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 if (pi0 < pend) stage[pi0] = padv;
                 if (pi0 + 64u < pend) stage[pi0 + 64u] = padv;
             }
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the asm writes are invisible to the compiler's counters
             TSTAMP(8);   // appends
 
             // ---- 7. Huffman coding of the list (rle.c:83-123, huffman.c:145-188): two items per lane and pass ----
 #pragma unroll 1
             for (uint32_t base = 0; base < nitems; base += (uint32_t)kPassItems) {
-                const uint2 pair = *reinterpret_cast<const uint2 *>(&stage[base + 2u * cl]);
-#if JPEGAMD_PREPAD
-                const uint32_t ia = pair.x, ib = pair.y;
-#else
-                const uint32_t rem = nitems - base;
-                uint32_t ia = pair.x, ib = pair.y;
-                if (rem < (uint32_t)kPassItems) {                 // the list's last pass: the lanes beyond it code padding items (no bits)
-                    ia = 2u * cl < rem ? ia : kItPadValue;
-                    ib = 2u * cl + 1u < rem ? ib : kItPadValue;
+#if JPEGAMD_SHORT_TAIL
+                if (nitems - base <= 64u) {                       // the list's tail: one item per lane
+                    const uint32_t it1 = stage[base + cl];
+                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_item, (int)it1, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+                    uint32_t e1, s1;
+                    code_item(it1, p1, s_code, e1, s1);
+                    uint32_t l1 = (e1 >> 8) & 0xFFu, h1 = s1, lo1 = 0u;
+                    const bool zrl1 = __ballot((e1 & 0x60u) != 0u) != 0ull;
+                    if (__builtin_expect(zrl1, 0)) {              // runs >= 16 (rle.c:99-103): ZRL symbols in front
+                        const uint32_t z1 = (e1 >> 5) & 3u;
+                        l1 += z1 * kZrlBits;
+                        nzrl += (uint32_t)wave_sum_i32((int)z1);
+                        unsigned long long a64 = (unsigned long long)s1 << 32;
+                        for (uint32_t q = 0; q < 3; ++q)
+                            if (q < z1) a64 = (a64 >> kZrlBits) | ((unsigned long long)(kZrlCode << (32u - kZrlBits)) << 32);
+                        h1 = (uint32_t)(a64 >> 32);
+                        lo1 = (uint32_t)a64;
+                    }
+                    const uint32_t incl1 = wave_incl_scan_u32(l1);
+                    const uint32_t bits1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
+                    // (64 items: <= 64 x 60 bits = 120 words -- make room as the long pass does)
+                    if (__builtin_expect(((cur_bits + bits1) >> 5) - wbase + 3u > (uint32_t)kWinStr, 0)) {
+                        const uint32_t done = (cur_bits >> 5) - wbase;
+                        if (done) {
+                            const uint32_t part = win[kTileRecWords + done];
+                            for (uint32_t j = cl; j < done; j += 64) *str_word(wbase + j) = win[kTileRecWords + j];
+#pragma unroll
+                            for (int i = 0; i < kWinWords / 64; ++i) win[i * 64 + cl] = 0u;
+                            if (cl == 0) win[kTileRecWords] = part;
+                            wbase += done;
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        }
+                    }
+                    const uint32_t rel1 = (uint32_t)(kTileRecWords * 32) + cur_bits + incl1 - l1 - wbase * 32u;
+                    window_or(win, rel1, h1, lo1, zrl1);
+                    cur_bits += bits1;
+                    break;
                 }
 #endif
+                const uint2 pair = *reinterpret_cast<const uint2 *>(&stage[base + 2u * cl]);
+                const uint32_t ia = pair.x, ib = pair.y;
                 // the item in front of a lane's first item: the second item of the lane before (lane 0: the pass before)
                 const uint32_t pa = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_item, (int)ib, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
                 carry_item = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
