@@ -659,10 +659,10 @@ int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64
     im.blocks_w = 1; im.blocks_h = 1; im.segs_per_row = 1; im.num_segs = 1;   // block (0,0) only
     im.tiles_per_row = 1; im.num_tiles = 1; im.tile_begin = 0; im.tile_end = 1; im.seg_begin = 0; im.seg_end = 1;
     int8_t *y_dev = nullptr; int16_t *zz_dev = nullptr; float *dct_dev = nullptr;
-    HIP_TRY(hipMalloc((void **)&y_dev, 64));
-    HIP_TRY(hipMalloc((void **)&zz_dev, 128));
-    HIP_TRY(hipMalloc((void **)&dct_dev, 256));
-    int err = launch_transform_and_entropy(e, im, true, y_dev, zz_dev, nullptr, nullptr);
+    int err = (int)hipMalloc((void **)&y_dev, 64);              // (every exit path below frees what was allocated)
+    if (!err) err = (int)hipMalloc((void **)&zz_dev, 128);
+    if (!err) err = (int)hipMalloc((void **)&dct_dev, 256);
+    if (!err) err = launch_transform_and_entropy(e, im, true, y_dev, zz_dev, nullptr, nullptr);
     if (!err) err = launch_dct_exact(y_dev, dct_dev, 1, nullptr);
     if (!err) err = (int)hipMemcpy(y, y_dev, 64, hipMemcpyDeviceToHost);
     if (!err) err = (int)hipMemcpy(zz, zz_dev, 128, hipMemcpyDeviceToHost);
@@ -674,7 +674,10 @@ int32_t first_block_taps(JpegAmdEncoder *e, const JpegAmdImage *img, int8_t y[64
 
 extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
     if (!dto) return JPEGAMD_ERR_ARG;
-    if (!g_ctx) return JPEGAMD_ERR_NOT_INIT;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_ctx) return JPEGAMD_ERR_NOT_INIT;
+    }
     if (dto->gb_phy_ptr != 0 || dto->rle_phy_ptr != 0) return JPEGAMD_ERR_ARG;
     uint64_t *size_dev = nullptr;
     JpegAmdEncoder *e = shared_context(dto->width > 0 ? dto->width : 1, dto->height > 0 ? dto->height : 1, &size_dev);
@@ -696,6 +699,11 @@ extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
 
     dto->huff_size = (uint32_t)st.jfif_bytes;
     dto->rle_count = (uint32_t)last_symbol_count(e);
+    // Stage counters (jpeg_compression.c:188-210 fills six), in nanoseconds.  The six stages are phases of ONE kernel here, so
+    // a plain build reports k_tile_encode's duration under cycles_dct, k_segment_merge under cycles_rle, k_finalize under
+    // cycles_huffman, and 0 for the rest.  A diagnostic build (-DJPEGAMD_STAMPS, JPEGAMD_STAMPS=1 in the environment) has
+    // in-kernel phase stamps: k_tile_encode's duration is then split by the phases' shares of the waves' time (zigzag is an
+    // addressing mode of the matrix operand: it has no phase and stays 0).
     dto->cycles_color_conversion = 0;
     dto->cycles_dct = st.ns_transform;
     dto->cycles_quantization = 0;
@@ -703,6 +711,28 @@ extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
     dto->cycles_rle = st.ns_entropy;
     dto->cycles_huffman = st.ns_pack;
     dto->cycles_total = st.ns_total;
+    if (e->stamps_dev) {
+        const int tiles = ((dto->height + 7) / 8) * (((dto->width + 7) / 8 + kTileBlocks - 1) / kTileBlocks);
+        const int wgs = (tiles + 7) / 8 < 512 ? (tiles + 7) / 8 : 512;
+        std::vector<unsigned long long> stamps((size_t)wgs * 8 * 16);
+        if (hipMemcpy(stamps.data(), e->stamps_dev, stamps.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            double ph[11] = {0};
+            for (size_t w = 0; w < (size_t)wgs * 8; ++w)
+                for (int i = 0; i < 11; ++i) ph[i] += (double)stamps[w * 16 + i];
+            double all = 0;
+            for (double v : ph) all += v;
+            if (all > 0) {                                            // (all zero: not a stamps build)
+                const double k = (double)st.ns_transform / all;
+                // phases: 0 loop, 1 wait rows + luma, 2 luma -> LDS, 3 MFMA, 4 quantise, 5 exact order, 6 counts, 7 ticket / row
+                // requests, 8 appends, 9 coding, 10 record / copy-out; the loop's own overhead (0, 7) goes with the colour stage
+                dto->cycles_color_conversion = (uint64_t)(k * (ph[0] + ph[1] + ph[2] + ph[7]));
+                dto->cycles_dct = (uint64_t)(k * ph[3]);
+                dto->cycles_quantization = (uint64_t)(k * (ph[4] + ph[5]));
+                dto->cycles_rle = (uint64_t)(k * (ph[6] + ph[8])) + st.ns_entropy;
+                dto->cycles_huffman = (uint64_t)(k * (ph[9] + ph[10])) + st.ns_pack;
+            }
+        }
+    }
 
     // First-block debug taps (jpeg_compression.c:150-169), host pointers.
     if (dto->y_phy_ptr || dto->dct_phy_ptr || dto->quant_phy_ptr || dto->zigzag_phy_ptr) {

@@ -58,31 +58,6 @@ __device__ __forceinline__ int luma_clamped(const ImageDesc &im, const uint8_t *
     return (int)(((w & 0xFF) * p[0] + ((w >> 8) & 0xFF) * p[1] + ((w >> 16) & 0xFF) * p[2]) >> 8);
 }
 
-// Luma = bits 15:8 of the dot product (the sum is < 2^16).  Shift + convert: the one-instruction
-// v_cvt_f32_ubyte1 form costs ~40 more live VGPRs in hipcc's schedule (197 vs 160, one wave per
-// SIMD less), and as inline asm right behind v_dot4 it reads a stale register on gfx950 (the
-// compiler's DOT->VALU hazard padding does not cover asm operands).
-__device__ __forceinline__ float ubyte1_f32(uint32_t x) { return (float)(int)(x >> 8); }
-
-// 8 pixels (24 bytes, 4-byte aligned) -> 8 luma values via v_dot4_u32_u8.  The dot product is
-// 256*Y + fraction (< 2^16), so Y = byte 1 of the result: v_cvt_f32_ubyte1 converts it in one op.
-__device__ __forceinline__ void luma_row8(const uint32_t *__restrict__ src, uint32_t w, float *y) {
-    const uint32_t d0 = src[0], d1 = src[1], d2 = src[2], d3 = src[3], d4 = src[4], d5 = src[5];
-    const uint32_t c0 = w & 0xFFu, c1 = (w >> 8) & 0xFFu, c2 = (w >> 16) & 0xFFu;
-    const uint32_t wA = w;                         // pixel in bytes 0..2
-    const uint32_t wB0 = c0 << 24, wB1 = c1 | (c2 << 8);          // byte 3 | bytes 0..1
-    const uint32_t wC0 = (c0 << 16) | (c1 << 24), wC1 = c2;       // bytes 2..3 | byte 0
-    const uint32_t wD = w << 8;                    // pixel in bytes 1..3
-    y[0] = ubyte1_f32(__builtin_amdgcn_udot4(d0, wA, 0u, false));
-    y[1] = ubyte1_f32(__builtin_amdgcn_udot4(d1, wB1, __builtin_amdgcn_udot4(d0, wB0, 0u, false), false));
-    y[2] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wC1, __builtin_amdgcn_udot4(d1, wC0, 0u, false), false));
-    y[3] = ubyte1_f32(__builtin_amdgcn_udot4(d2, wD, 0u, false));
-    y[4] = ubyte1_f32(__builtin_amdgcn_udot4(d3, wA, 0u, false));
-    y[5] = ubyte1_f32(__builtin_amdgcn_udot4(d4, wB1, __builtin_amdgcn_udot4(d3, wB0, 0u, false), false));
-    y[6] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wC1, __builtin_amdgcn_udot4(d4, wC0, 0u, false), false));
-    y[7] = ubyte1_f32(__builtin_amdgcn_udot4(d5, wD, 0u, false));
-}
-
 // ------------------------------------------------------------------------------------
 // Wave helpers (wave = 64 lanes)
 // ------------------------------------------------------------------------------------

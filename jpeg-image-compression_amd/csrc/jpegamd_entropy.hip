@@ -251,7 +251,10 @@ __global__ __launch_bounds__(64 * kWavesE) void k_segment_merge(const MergeArgs 
         }
     }
     if (lane < 8) {
+        // (16-bit counts: a segment's Huffman string cannot hold that many 0xFF bytes -- every code but the rare run-15 ones has
+        //  a zero in it -- but a count that did not fit must not pass silently)
         if (have) a.seg.ffin[(size_t)seg * 8 + lane] = (uint16_t)min(mine, 65535u);
+        if (have && mine > 65535u) atomicOr(a.status, 2u);
         s_gmeta[wave][2 + lane] = mine;
     }
     if (lane == 0) { s_gmeta[wave][0] = seg_bits; s_gmeta[wave][1] = have ? seg_edge : 0u; }   // (no segment: no bits, no ones at either end)
