@@ -19,8 +19,8 @@ Workloads (`--workload`, default `auto`):
              launch per step; every finished bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
 Reference quantisation table (Q=50) unless --quality says otherwise; pixel rows resident in HBM; output = complete
 JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_encode -> k_segment_merge -> k_finalize) over the
-step's images.  Launches alternate over `--streams` encoder contexts / HIP streams (default 4) so the latency-bound tail
-kernels of one launch overlap the transform of the next; every step is still a complete encode.  With N > 1 every rank
+step's images, on one HIP stream by default (`--streams`: k_tile_encode is a persistent kernel that fills the GPU; launches on
+several streams queue behind each other's workgroups and were measured slower); every step is a complete encode.  With N > 1 every rank
 encodes its own images (weak scaling, no data-path collective inside the encode) and the finished bitstreams are
 collected at rank 0 with one asynchronous RCCL gather per `--gather-every` images
 (jpegamd.sharding.BatchedStreamGather), overlapped with the following steps.
@@ -75,9 +75,14 @@ def parse_args():
     ap.add_argument("--images-per-launch", type=int, default=0, choices=[0, 1, 2, 4, 8],
                     help="images coded by ONE launch of each kernel (jpegamd_encode_batch_async); 0 = 8 (image8192 then codes 8 images per step)")
     ap.add_argument("--roofline-idle-ms", type=float, default=250.0, help="idle time in front of the second single-stream roofline pass")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="HIP streams (one encoder context each) the images alternate over; >1 lets the latency-bound tail "
-                         "kernels of one image overlap the transform kernel of the next")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams (one encoder context each) the launches alternate over.  One by default: k_tile_encode is a "
+                         "persistent kernel that fills the GPU, so launches on several streams only queue behind each other's "
+                         "workgroups (measured: 4 streams 0.544, 2 streams 0.567, 1 stream 0.534 ms per step of eight images)")
+    ap.add_argument("--burn-in-ms", type=float, default=40.0,
+                    help="untimed steps in front of the W warm-up steps, for this many milliseconds: the first ~12 ms of sustained load "
+                         "after an idle period run 10-30 %% slow on MI355X (power-management transient, profiles/r03_load_onset.txt), and "
+                         "W = 5 steps are 2 ms.  0 = none")
     ap.add_argument("--force-gather", action="store_true", help="run the N > 1 gather path with a one-rank group (rehearsal on one GPU)")
     ap.add_argument("--gather-every", type=int, default=32,
                     help="N > 1: images per rank carried by one gather to rank 0 (few, large collectives)")
@@ -311,10 +316,21 @@ def main():
                         continue
                     raise RuntimeError(f"bench.py: an encode in the {where} did not fit its output buffer ({err})")
 
+        # burn-in (untimed, part of the set-up like the input generation): steps until the device has been under sustained load
+        # for --burn-in-ms; the W warm-up steps follow without a pause
+        burn_steps = 0
+        if args.burn_in_ms > 0:
+            t_b = time.perf_counter()
+            while (time.perf_counter() - t_b) * 1e3 < args.burn_in_ms:
+                for _ in range(8):
+                    step(burn_steps)
+                    burn_steps += 1
+                tstreams[0].synchronize()
+        W0 = burn_steps                                              # steps are numbered on from the burn-in (buffers rotate with the step number)
         for i in range(W):
-            step(i)
+            step(W0 + i)
         drain()
-        if W:
+        if W or burn_steps:
             check_capacity("warm-up")
 
         n_timed = K * ips
@@ -326,7 +342,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(K):
-            step(W + i)
+            step(W0 + W + i)
         t_issued = time.perf_counter()                               # host-side cost of enqueueing the K steps
         drain()
         if dist is not None:
@@ -338,7 +354,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
-        last = (W + K) * ips - 1
+        last = (W0 + W + K) * ips - 1
         last_ctx = (last // B) % nstreams
         def finish_timed(e):
             try:
@@ -485,6 +501,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
+            "burn_in": {"ms": args.burn_in_ms, "steps": burn_steps},
             "ms_per_step": round(elapsed / K * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
