@@ -118,7 +118,7 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 #endif
 
 #ifndef JPEGAMD_TICKET_AT
-#define JPEGAMD_TICKET_AT 1           // where the next tile's ticket is requested: 0 top of the iteration, 1 behind the luma conversion, 2 behind the MFMAs
+#define JPEGAMD_TICKET_AT 2           // where the next tile's ticket is requested: 0 top of the iteration, 1 behind the luma conversion, 2 behind the MFMAs
 #endif
 #ifndef JPEGAMD_STASH_LATE
 #define JPEGAMD_STASH_LATE 0

@@ -15,6 +15,6 @@ for ipl in 8 1; do
   python3 - <<PY
 import json
 d=json.load(open("$O/trace$ipl.json")); r=d["roofline"]
-print("bench: value %.0f  frac %.3f  transform %.2f merge %.2f finalize %.2f sum %.2f per-image %.2f  %s" % (d["value"], r["frac"], r["kernel_us"], r["entropy_us"], r["pack_us"], r["sum_kernels_us"], r["per_image_us"], d["parity"]))
+print("bench: value %.0f  frac %.3f  transform %.2f merge %.2f finalize %.2f sum %.2f per-image %.2f  %s" % (d["value"], r["frac"], r["kernel_us"], r["merge_us"], r["finalize_us"], r["sum_kernels_us"], r["per_image_us"], d["parity"]))
 PY
 done
