@@ -117,18 +117,6 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 #define TSTAMP(i) do { } while (0)
 #endif
 
-#ifndef JPEGAMD_TICKET_AT
-#define JPEGAMD_TICKET_AT 2           // where the next tile's ticket is requested: 0 top of the iteration, 1 behind the luma conversion, 2 behind the MFMAs
-#endif
-#ifndef JPEGAMD_STASH_LATE
-#define JPEGAMD_STASH_LATE 0
-#endif
-#ifndef JPEGAMD_THIRD_ALWAYS
-#define JPEGAMD_THIRD_ALWAYS 1
-#endif
-#ifndef JPEGAMD_SHORT_TAIL
-#define JPEGAMD_SHORT_TAIL 1          // a list's last 64 items or fewer are coded one per lane (half the work of a two-per-lane pass)
-#endif
 #ifndef JPEGAMD_TILE_GROUPS
 #define JPEGAMD_TILE_GROUPS 64
 #endif
@@ -235,9 +223,8 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt0)::"memory");
 #endif
 
-#ifndef JPEGAMD_PROLOGUE_ROWS_FIRST
-#define JPEGAMD_PROLOGUE_ROWS_FIRST 1      // the first tile's pixel rows are requested AHEAD of the workgroup's tables: the two HBM latencies overlap
-#endif
+// The workgroup's tables go to LDS BEHIND the first tile's row requests: the two HBM latencies of the prologue overlap
+// (-11 us per launch of eight pictures, -1.5 us per single one).
 #define JPEGAMD_LOAD_TABLES() \
         { \
             const int t = (int)threadIdx.x; \
@@ -256,10 +243,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             } \
         } \
         __syncthreads(); \
-
-#if !JPEGAMD_PROLOGUE_ROWS_FIRST
-    JPEGAMD_LOAD_TABLES()
-#endif
 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
@@ -299,8 +282,8 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         const int chunks = full_steps + ((rem > 0 && ((g + full_steps) & gmask) < rem) ? 1 : 0);
         return chunks * kWavesT - (g == last_owner ? nchunks * kWavesT - ntl : 0);
     };
-    // (Drawing from partner groups on other XCDs once the own group is dry was tried, 1-3 levels deep: no gain -- the spread
-    // INSIDE a group, one tile-time, dominates.  profiles/r02_notes_experiments.txt)
+    // (Drawing from partner groups on other XCDs once the own group is dry was tried in rounds 2 and 3, 1-3 levels deep: no gain --
+    // the spread INSIDE a group, one tile-time, dominates.  profiles/r02_notes_experiments.txt, r03_notes_experiments.txt)
     int cur_grp = grp, cur_hi = tiles_of(grp), cur_waves = waves_of(grp);
     const auto to_tile = [&](int li) {
         const int k = li / kWavesT;
@@ -351,9 +334,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     int tile = first < cur_hi ? to_tile(first) : im.tile_begin;     // picture tile of the iteration (carried: to_tile() once per tile)
     TileGeo tg = geo(tile);
     if (first < cur_hi && tg.interior) request_rows(tg, raw);
-#if JPEGAMD_PROLOGUE_ROWS_FIRST
     JPEGAMD_LOAD_TABLES()
-#endif
 #undef JPEGAMD_LOAD_TABLES
 #ifdef JPEGAMD_STAMPS
     unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
@@ -367,9 +348,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         const int py0 = by * 8, px0 = bx * 8;
         const bool active = b < nblk, interior = tg.interior;
         int nexact = 0;
-#if JPEGAMD_TICKET_AT == 0
-        const uint32_t ticket_v = ticket();
-#endif
         TSTAMP(0);   // loop overhead / geometry
         // ---- 1. pixels -> B fragments ----------------------------------------------------------
         f16x8 bfrag[4];
@@ -385,7 +363,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     bfrag[s][j] = (_Float16)(float)(luma_clamped(im, im.batch_pixels[tg.img], px0 + j, py0 + 2 * s + h) - 128);
         }
         TSTAMP(1);   // wait for the prefetched rows + luma
-#if !JPEGAMD_STASH_LATE
         {
         uint32_t sl;                           // (an opaque lane id: the stash addresses are not worth four registers across the whole loop)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl));
@@ -393,10 +370,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 #pragma unroll
         for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&sp0[2 * s * 132]) = bfrag[s];     // (one address, four immediate offsets)
         }
-#endif
-#if JPEGAMD_TICKET_AT == 1
-        const uint32_t ticket_v = ticket();
-#endif
+        TSTAMP(2);   // luma -> LDS
         if (kTaps && active && out.tap_y) {
             int8_t *ty = out.tap_y + ((size_t)by * im.blocks_w + bx) * 64;
 #pragma unroll
@@ -439,22 +413,11 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             }
         }
 
-        // the luma stash for the exact-order path goes to LDS behind the MFMAs' operand reads: its four 16-byte writes then
-        // overlap the matrix pipe instead of delaying it
-#if JPEGAMD_STASH_LATE
-        {
-        uint32_t sl;                           // (an opaque lane id: the stash addresses are not worth four registers across the whole loop)
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl));
-        uint32_t *const sp0 = &s_pix[wave][(sl >> 5) * 132 + (sl & 31) * 4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&sp0[2 * s * 132]) = bfrag[s];     // (one address, four immediate offsets)
-        }
-#endif
-        TSTAMP(2);
-        TSTAMP(3);   // MFMA, luma -> LDS
-#if JPEGAMD_TICKET_AT == 2
-        const uint32_t ticket_v = ticket();
-#endif
+        // (the luma stash behind the MFMAs' operand reads instead of in front of them keeps the 16 operand registers alive into
+        //  the quantiser: 15 spilled registers, 8 % slower)
+        TSTAMP(3);   // MFMA
+        const uint32_t ticket_v = ticket();          // (requested here, collected behind the counts: at the top of the iteration or behind the luma
+                                                     //  conversion measured 1.2 % slower -- a wave then sits longer on a reserved, unstarted tile at the end)
         // ---- 3. quantise with the guard band, one GROUP of 8 sites at a time -----------------------
         // Site s = 16H + r of lane (h, b) holds zigzag position 16 * (s >> 3) + 8 * h + (s & 7): group G = s >> 3
         // covers zigzag 16G .. 16G + 15 across the two lanes of a block.  Every instruction of any wave costs one
@@ -687,7 +650,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             // ---- 7. Huffman coding of the list (rle.c:83-123, huffman.c:145-188): two items per lane and pass ----
 #pragma unroll 1
             for (uint32_t base = 0; base < nitems; base += (uint32_t)kPassItems) {
-#if JPEGAMD_SHORT_TAIL
                 if (nitems - base <= 64u) {                       // the list's tail: one item per lane
                     const uint32_t it1 = stage[base + cl];
                     const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_item, (int)it1, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
@@ -725,7 +687,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     cur_bits += bits1;
                     break;
                 }
-#endif
                 const uint2 pair = *reinterpret_cast<const uint2 *>(&stage[base + 2u * cl]);
                 const uint32_t ia = pair.x, ib = pair.y;
                 // the item in front of a lane's first item: the second item of the lane before (lane 0: the pass before)
@@ -763,7 +724,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     // join the lane's two strings: (bits_a : bits_b >> len_a), <= 54 bits
                     const uint32_t hi = sa | __builtin_amdgcn_alignbit(0u, sb, la);
                     const uint32_t lo = __builtin_amdgcn_alignbit(sb, 0u, la);
-                    window_or(win, rel, hi, lo, JPEGAMD_THIRD_ALWAYS ? true : (__ballot((rel & 31u) + lab > 64u) != 0ull));
+                    window_or(win, rel, hi, lo, true);
                 } else {
                     // symbol by symbol, each with its ZRLs in front (huffman.c:158-188 codes them as ordinary symbols)
                     const auto with_zrl = [&](uint32_t bits, uint32_t z, uint32_t &hi, uint32_t &lo) {
