@@ -102,13 +102,18 @@ __device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeig
 // The stamps do NOT drain vmcnt, so the prefetch / store overlap stays as shipped;
 // a phase is charged with whatever its own s_waitcnt instructions wait for.
 #ifdef JPEGAMD_STAMPS
+// (the phase sums live in LDS, added to by lane 0 alone: eleven scalar accumulators cost the kernel spilled registers, and a
+//  scratch reload -- a vector memory operation behind the closing store -- distorted the very profile they were for)
 #define TSTAMP(i)                                                                             \
     do {                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        unsigned long long t_;                                                                \
+        unsigned long long t_, sv_;                                                           \
+        unsigned va_, vd_;                                                                    \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-        st_sum[i] += t_ - st_last;                                                            \
-        st_last = t_;                                                                         \
+        const unsigned d_ = (unsigned)t_ - st_last;                                           \
+        st_last = (unsigned)t_;                                                               \
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tv_mov_b32 %1, %3\n\tv_mov_b32 %2, %4\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0" \
+                     : "=&s"(sv_), "=&v"(va_), "=&v"(vd_) : "s"(st_lds + 4u * (i)), "s"(d_) : "memory");          \
         __builtin_amdgcn_sched_barrier(0);                                                    \
     } while (0)
 #elif defined(JPEGAMD_MARKS)      // static instruction census: markers in the .s file (tools/isa_census.py)
@@ -337,9 +342,13 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     JPEGAMD_LOAD_TABLES()
 #undef JPEGAMD_LOAD_TABLES
 #ifdef JPEGAMD_STAMPS
-    unsigned long long st_sum[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last, st_rt1;
-    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_last)::"memory");
-    const unsigned long long st_c1 = st_last;
+    __shared__ unsigned s_st[kWavesT][16];
+    if (lane < 16) s_st[wave][lane] = 0u;
+    const unsigned st_lds = (unsigned)(uintptr_t)&s_st[wave][0];           // LDS byte address of this wave's phase sums
+    unsigned st_last;
+    unsigned long long st_rt1, st_c1;
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt1), "=s"(st_c1)::"memory");
+    st_last = (unsigned)st_c1;
 #endif
 
 #pragma unroll 1
@@ -787,7 +796,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_rt2), "=s"(st_c2)::"memory");
         if (lane == 0 && out.stamps) {
             unsigned long long *o = out.stamps + (size_t)(blockIdx.x * kWavesT + wave) * 16;
-            for (int i = 0; i < 11; ++i) o[i] = st_sum[i];
+            for (int i = 0; i < 11; ++i) o[i] = s_st[wave][i];
             o[11] = st_rt0; o[12] = st_rt1; o[13] = st_rt2; o[14] = st_c2 - st_c1;
         }
     }
