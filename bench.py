@@ -378,7 +378,7 @@ def main():
         # kernels of different images share the GPU in the timed region and stretch.  A short single-stream pass over the
         # same inputs gives each kernel alone (this is what rocprofv3 --stats sees for `bench.py --streams 1`).
         # Two such passes: one right behind the timed region (the GPU still in the power / clock state of sustained load: the
-        # HBM-bound k_tile_transform runs ~15-20 % longer there, the other two kernels a little shorter) and one after a short
+        # k_tile_encode runs a few percent shorter there, the other two kernels a little shorter) and one after a short
         # idle.  `roofline` is built from the second, the state a kernel trace of `bench.py --streams 1` sees (its launch gaps
         # keep the GPU a quarter idle); the first is reported beside it as `sustained`.
         sustained, single_ns = None, None

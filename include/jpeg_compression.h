@@ -86,8 +86,8 @@ typedef struct JpegAmdStats {
     uint64_t exact_fallbacks;   /* coefficients recomputed in the reference's float order */
     /* With profiling on (jpegamd_encoder_set_profiling) every kernel is launched with its own begin / end events
        (hipExtLaunchKernelGGL): the three figures are the kernels' OWN durations, what a kernel trace shows. */
-    uint64_t ns_transform;      /* k_tile_transform: luma + DCT + quantisation + zigzag + symbol lists */
-    uint64_t ns_entropy;        /* k_entropy: run/size symbols -> Huffman bit strings per segment */
+    uint64_t ns_transform;      /* k_tile_encode: luma + DCT + quantisation + zigzag + run/size symbols + Huffman coding, per tile */
+    uint64_t ns_entropy;        /* k_segment_merge: the tiles' bit strings -> one per segment (the field keeps its round-1 name) */
     uint64_t ns_pack;           /* k_finalize: bit / stuffing offsets, stitch, 0xFF stuffing, container */
     uint64_t ns_total;          /* begin of the first kernel .. end of the last: the three durations plus the launch gaps between them */
 } JpegAmdStats;

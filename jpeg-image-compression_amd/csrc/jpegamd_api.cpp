@@ -51,7 +51,7 @@ struct JpegAmdEncoder {
     int prefix_w = -1, prefix_h = -1, prefix_q = -1;
     // profiling: a ring of event quadruples so callers can time many async encodes and read
     // the per-kernel durations after ONE synchronisation
-    struct EventSet { hipEvent_t ev[6]; };     // begin / end of k_tile_transform, k_entropy, k_finalize (the kernels' own timestamps)
+    struct EventSet { hipEvent_t ev[6]; };     // begin / end of k_tile_encode, k_segment_merge, k_finalize (the kernels' own timestamps)
     std::vector<EventSet> ring;
     uint64_t calls = 0;          // encodes enqueued since profiling was (re)enabled
     int last_slot = -1;

@@ -6,7 +6,7 @@
 // with a plain store: no atomics, no pre-zeroing.  Where a segment's bytes go depends on (a) the bits of all earlier
 // segments -- a direct sum of their bit counts, final when this kernel starts -- and (b) the 0xFF bytes owned by all
 // earlier segments, because each is followed by a stuffed 0x00.  (b) depends on every earlier segment's byte phase, which
-// is why round 1 needed a separate counting kernel between two dependent launches.  Now k_entropy leaves, per segment,
+// is why round 1 needed a separate counting kernel between two dependent launches.  Now k_segment_merge leaves, per segment,
 // the number of 0xFF bytes lying wholly inside it for each of the 8 phases, plus its first 8 and last 7 bits (what the byte
 // straddling two segments is made of); a workgroup scans the earlier segments' bit counts (phase of each), picks the matching
 // counts, adds the straddling bytes, and has both offsets -- chain-free, from per-segment numbers alone.
@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t fin_tail_bits(const View &a, int s, int need
     return val;
 }
 
-// Owned 0xFF bytes of segment t given its byte phase p (= bit offset & 7): those wholly inside it (counted by k_entropy)
+// Owned 0xFF bytes of segment t given its byte phase p (= bit offset & 7): those wholly inside it (counted by k_segment_merge)
 // plus the byte that straddles its start -- 0xFF iff the last p bits in front of it and its first 8 - p bits are all ones.
 // edge = (first 8 bits << 8) | last 7 bits of a segment's own string.  A segment shorter than 8 bits is "00 1010" (one
 // flat block): it has no leading one, and its tail ends in 0, so neither side can complete an 0xFF across it.

@@ -12,8 +12,8 @@ namespace jpegamd {
 
 // ---- geometry of the device pipeline ---------------------------------------------------
 // block   8x8 pixels
-// tile    32 consecutive blocks of one block row: one wave-iteration of k_tile_transform, one 32-column MFMA operand
-// segment 8 consecutive tiles of one block row (<= 256 blocks): one wave of k_entropy, the unit of bitstream ownership
+// tile    32 consecutive blocks of one block row: one wave-iteration of k_tile_encode, one 32-column MFMA operand, one bit string
+// segment 8 consecutive tiles of one block row (<= 256 blocks): one wave of k_segment_merge, the unit of bitstream ownership
 constexpr int kTileBlocks = 32;
 #ifndef JPEGAMD_SEG_TILES
 #define JPEGAMD_SEG_TILES 8
@@ -111,7 +111,7 @@ struct ImageDesc {
     int32_t fast_ok;           // pixels % 4 == 0 && row_stride % 4 == 0
 };
 
-// What k_entropy leaves per segment (and what one image sharded over GPUs exchanges, besides the bit strings).
+// What k_segment_merge leaves per segment (and what one image sharded over GPUs exchanges, besides the bit strings).
 struct SegArrays {
     uint32_t *words;            // [num_segs][words_stride] MSB-first bit string, unstuffed
     uint32_t words_stride;      // seg_cap_words(tiles per segment of the launch)
@@ -162,7 +162,7 @@ struct FinalizeArgs {
     int32_t num_segs;               // per image
     int32_t num_chunks;             // per image: workgroups = batch * ceil(num_segs / 16)
     int32_t batch;
-    int32_t use_groups;             // the group aggregates are valid for these segments (whole images coded by k_entropy, num_segs % kSegGroup == 0)
+    int32_t use_groups;             // the group aggregates are valid for these segments (whole images merged by k_segment_merge, num_segs % kSegGroup == 0)
     uint8_t *out[kMaxBatch];
     uint64_t out_capacity;          // of every output
     uint64_t *out_size[kMaxBatch];  // device

@@ -1,5 +1,5 @@
 #!/bin/bash
-# in-kernel stamp profile of k_tile_transform (diagnostic builds build_variants/lib_stamps*.so)
+# in-kernel stamp profile of k_tile_encode (diagnostic builds build_variants/lib_stamps*.so)
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/stamps

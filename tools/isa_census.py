@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction census of k_tile_transform<false> between the TSTAMP markers.
+"""Static instruction census of k_tile_encode<false> between the TSTAMP markers.
   hipcc ... -DJPEGAMD_MARKS --save-temps=obj -c csrc/jpegamd_tile_pipeline.hip ; isa_census.py file.s"""
 import re
 import sys

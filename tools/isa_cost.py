@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static VALU-cycle estimate of k_tile_transform<false> between the TSTAMP markers, with the measured issue costs
+"""Static VALU-cycle estimate of k_tile_encode<false> between the TSTAMP markers, with the measured issue costs
 (profiles/r02_issue_model_forms.txt): VOP2/VOP1 add/sub/xor/and/or/mov/mul_f32/add_f32/fmac/fma with VGPR operands 2 cycles,
 every other VALU form 4, MFMA 8 (issue), DPP / SDWA 4.  Straight-line count: every branch of the marked region is summed."""
 import re, sys
