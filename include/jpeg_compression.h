@@ -169,7 +169,7 @@ uint64_t jpegamd_synth_bmp(int32_t width, int32_t height, uint32_t seed, int32_t
  * natural_c/src/core/jpeg_tables.c:3-12; other values = its libjpeg scaling, an extension). */
 int32_t jpegamd_debug_quant_table(int32_t quality, uint8_t *table);
 
-/* Constants of the fast quantiser, indexed by ZIGZAG position (one bias for all; the rigorous guard band delta by raster k). */
+/* Constants of the fast quantiser: qmul, qthr, bias float[64] by ZIGZAG position; the rigorous guard band delta, double[64], by raster k. */
 int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, float *bias, double *delta);
 /* Zero thresholds of the split pipeline's coefficient groups ([group 0..3][lane half 0..1], group G of half h =
  * zigzag 16G+8h .. +7): a tile whose |LUT sums| all stay below them skips that group's quantiser entirely. */

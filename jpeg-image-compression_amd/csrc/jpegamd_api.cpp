@@ -91,7 +91,7 @@ extern "C" int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float
     derive_mfma_tables(t, mt, d);
     if (qmul) std::memcpy(qmul, mt->qmul, sizeof(mt->qmul));
     if (qthr) std::memcpy(qthr, mt->qthr, sizeof(mt->qthr));
-    if (bias) *bias = mt->bias;
+    if (bias) std::memcpy(bias, mt->bias, sizeof(mt->bias));
     if (delta) std::memcpy(delta, d, sizeof(d));
     delete mt;
     return JPEGAMD_OK;

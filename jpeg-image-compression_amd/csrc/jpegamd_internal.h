@@ -76,10 +76,9 @@ constexpr int kTileOverCap = ((kTileBlocks * kMaxBlockBits + 31) / 32 + 2 + 63) 
 struct MfmaTables {
     uint32_t afrag[kAFragWords];   // kMfmaScale * LUT-product matrix as two integer-valued binary16 terms (lo 2^-11, hi), MFMA A-operand order
     float qmul[64];                // by zigzag position z: M_z = K / (q * kMfmaScale)  (the MFMA output is kMfmaScale * LUT sum)
-    float qthr[64];                // (bias - 0.5) + delta_z
+    float qthr[64];                // flag threshold 2 (bias_z - 0.5), exactly (the kernel derives it as fma(2, bias_z, -1))
     float qstep[64];               // (float) q, by zigzag position
-    float bias;                    // 0.5 + max_z delta_z
-    float pad[3];
+    float bias[64];                // by zigzag position: 0.5 + delta_z (with margin) -- a band of delta_z on EITHER side of a rounding tie
     float grp_thr[8];              // [group G][lane half h]: |MFMA output| below it => zigzag 16G+8h .. +7 all quantise to an unflagged 0
     float flag_thr[8];             // [group G][lane half h]: max qthr over zigzag 16G+8h .. +7
 };

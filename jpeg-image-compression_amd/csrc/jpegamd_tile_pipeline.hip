@@ -207,14 +207,14 @@ template <bool kTaps>
 __global__ __launch_bounds__(64 * kWavesT) __attribute__((amdgpu_waves_per_eu(JPEGAMD_TILE_WAVES, JPEGAMD_TILE_WAVES)))
 void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched sch) {
     __shared__ __attribute__((aligned(16))) uint32_t s_afrag[kAFragWords];
-    // s_qt[0..127]: (multiplier, tie threshold) by zigzag position; [128 + 16 h + G]: zero threshold of group G for lane half h
+    // s_qt[0..127]: (multiplier, bias) by zigzag position; [160 + 16 h + 32 G + j]: flag threshold (2 bias - 1) of zigzag 16 G + 8 h + j; [128 + 16 h + G]: zero threshold of group G for lane half h
     // (|acc| below it => every site of the group quantises to an unflagged 0), [132 + 16 h + G]: the largest tie threshold of the
     // group's sites (fract(zc) above it => no site is flagged).  One layout with 64 bytes per lane half: one address register.
-    __shared__ __attribute__((aligned(16))) float s_qt[128 + 32];
+    __shared__ __attribute__((aligned(16))) float s_qt[128 + 32 + 128];
     __shared__ float s_qstep[64];
     __shared__ float s_cos[64];
     __shared__ uint32_t s_zz[64];               // zigzag position -> raster index (exact-order path)
-    __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][64];   // exact-order path: the 64 terms of one coefficient
+    __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][4 * 64]; // exact-order path: the 64 terms of four coefficients
     // The tile's centred luma (binary16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
     // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
     // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
@@ -240,7 +240,8 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             for (int i = t; i < kCodeWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(s_code)[i] = csrc[i]; \
             for (int i = t; i < kWavesT * kWinWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(&s_win[0][0])[i] = make_uint4(0u, 0u, 0u, 0u); \
             if (t < 64) { \
-                s_qt[2 * t] = out.tables->qmul[t]; s_qt[2 * t + 1] = out.tables->qthr[t]; \
+                s_qt[2 * t] = out.tables->qmul[t]; s_qt[2 * t + 1] = out.tables->bias[t]; \
+                s_qt[160 + 16 * ((t >> 3) & 1) + 32 * (t >> 4) + (t & 7)] = out.tables->qthr[t]; \
                 s_qstep[t] = out.tables->qstep[t]; \
                 s_cos[t] = kCosFM[t]; \
                 s_zz[t] = kZZ[t]; \
@@ -252,8 +253,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
     const int h = lane >> 5, b = lane & 31;
-    float bias;                                 // in a VGPR: v_fma_f32 with three VGPR operands issues in 2 cycles, with an SGPR operand in 4 (profiles/r02_issue_model_forms.txt)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(bias) : "s"(out.tables->bias));
     const LumaWeights lw = luma_weights(im.weights);
     const uint32_t luma_kc = 0xFFFF8000u;
     const float *q_lane = &s_qt[16 * h];
@@ -438,14 +437,12 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         int n[32];
         uint32_t flagbits = 0;                                      // bit s: site s of this lane is within delta of a rounding tie
         bool gact[4];
-        float dc_sum = 0.0f;                                        // kMfmaScale x the block's pixel sum (lanes h == 0), exact
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
             gact[G] = true;
             float a8[8];                                            // the group's LUT sums (times kMfmaScale)
 #pragma unroll
             for (int j = 0; j < 8; ++j) a8[j] = JPEGAMD_ACC(8 * G + j);
-            if (G == 0) dc_sum = a8[0];
             if (G > 0) {                                            // |sum| below the group's zero threshold in every lane?
                 float m = fmaxf(fabsf(a8[0]), fabsf(a8[1]));
 #pragma unroll
@@ -453,36 +450,42 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 gact[G] = __ballot(m >= q_lane[128 + G]) != 0ull;
             }
             if (gact[G]) {
-                float fr[8], th[8];
+                float fr[8];
+                // DC (zigzag 0: site 0 of lanes h == 0).  Its LUT sum S is an exact integer and the reference's value has a closed form,
+                // sign(S) floor((|S| + 4 q) / 8 q): the scale 0.25 * 0.707107^2 lies 6.2e-7 ABOVE 1/8, which pushes the ties S = 4 q (2 m + 1)
+                // away from zero by ten float32 steps and nothing else across a tie (checked for every S and every q in 1 .. 255 by
+                // tests/test_host.py::test_dc_closed_form).  floor(|z| + 0.5 + delta) is that value, so the DC lanes quantise |S|,
+                // take the sign afterwards and never flag: rounds 1-2 flagged one DC in 128 (z is a multiple of ~1/128 at Q=50) and
+                // recomputed it in the reference's own operations -- 22 % of the tiles ran the flag compares and a float division for it.
+                const unsigned long long dc_lanes = 0x00000000FFFFFFFFull;
+                float a0 = a8[0];
+                if (G == 0) asm("v_cndmask_b32_e64 %0, %1, |%1|, %2" : "=v"(a0) : "v"(a8[0]), "s"(dc_lanes));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int st = 8 * G + j;
                     const float2 q = reinterpret_cast<const float2 *>(q_lane)[16 * G + j];
-                    const float zc = fmaf(a8[j], q.x, bias);                // z + 0.5 + delta
+                    const float zc = fmaf(j == 0 ? a0 : a8[j], q.x, q.y);   // z + 0.5 + delta_z (three VGPR operands: the 2-cycle form, profiles/r02_issue_model_forms.txt)
                     n[st] = floor_to_int(zc);
                     fr[j] = __builtin_amdgcn_fractf(zc);
-                    th[j] = q.y;
+                }
+                if (G == 0) {
+                    const int sg = (int)(__builtin_bit_cast(uint32_t, a0) ^ __builtin_bit_cast(uint32_t, a8[0])) >> 31;    // -1 in the DC lanes with S < 0
+                    n[0] = (n[0] ^ sg) - sg;
+                    asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(fr[0]) : "s"(dc_lanes));                                // a DC is never flagged
                 }
                 // Flags are rare (0.4 per tile): one min tree over the fractions against the group's largest threshold decides
                 // for the whole wave whether the per-site compares (16 instructions) are needed at all.
                 const float fmin8 = fminf(fminf(__builtin_fminf(fr[0], fminf(fr[1], fr[2])), fminf(fr[3], fminf(fr[4], fr[5]))), fminf(fr[6], fr[7]));
-                if (__ballot(fmin8 <= q_lane[132 + G]) != 0ull)
+                if (__ballot(fmin8 <= q_lane[132 + G]) != 0ull) {
+                    float th[8];                                             // (read here, two 16-byte reads, not carried from above)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) th[j] = q_lane[160 + 32 * G + j];
                     flagbits |= shift_in_le8(0u, fr, th) << (8 * G);        // bit j: site 8G + j is within delta of a tie
+                }
             } else if (kTaps) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) n[8 * G + j] = 0;
             }
-        }
-        // DC (zigzag 0, lanes h == 0): its LUT sum is an exact integer, so the reference's value follows from two
-        // float operations in the lane itself -- done only when some DC sits within delta of a tie (ties are
-        // frequent here: sum * (K/q) is a multiple of ~1/128 at Q=50), never through the cooperative path.
-        {
-            const bool dcflag = (h == 0) && (flagbits & 1u);
-            if (__ballot(dcflag) != 0ull) {
-                const int dc_exact = ref_quantise(__fmul_rn(ref_scale(0, 0), __fmul_rn(dc_sum, 1.0f / kMfmaScale)), s_qstep[0]);   // the scaled sum is exact, and so is 2^-11 of it
-                if (dcflag) n[0] = dc_exact;
-            }
-            if (h == 0) flagbits &= ~1u;
         }
         if (!active) flagbits = 0u;
         TSTAMP(4);   // quantise
@@ -501,32 +504,73 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             int el;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
             const uint32_t *pix_lane = &s_pix[wave][(el >> 3) * 132 + ((el & 7) >> 1)];
-            while (fm) {
-                const int fl = __ffsll((long long)fm) - 1;
-                fm &= fm - 1;
-                uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)flagbits, fl);
-                while (bits) {
-                    const int st = __ffs((int)bits) - 1;
-                    bits &= bits - 1;
-                    const int z = 16 * (st >> 3) + 8 * (fl >> 5) + (st & 7);
-                    const int k = __builtin_amdgcn_readfirstlane((int)s_zz[z]), u = k >> 3, v = k & 7;
-                    const uint32_t pw = pix_lane[(fl & 31) * 4];
-                    const float pix = (float)__builtin_bit_cast(_Float16, (uint16_t)((el & 1) ? pw >> 16 : pw));
-                    const float coef = exact_coef_float_lds(pix, u, v, s_cos, s_terms[wave], el);
-                    const int val = ref_quantise(coef, s_qstep[z]);
-                    ++nexact;
-                    if (kTaps && el == fl) exact_mask |= 1ull << k;
-                    const int jj = st & 7;
-                    switch (st >> 3) {                              // uniform: only the 8 registers of the site's group are touched
-#define JPEGAMD_PUT(G)                                                                                    \
-    case G:                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) n[8 * G + j] = (j == jj && el == fl) ? val : n[8 * G + j]; \
-        break;
-                        JPEGAMD_PUT(0) JPEGAMD_PUT(1) JPEGAMD_PUT(2) JPEGAMD_PUT(3)
-#undef JPEGAMD_PUT
+            float *const terms = &s_terms[wave][0];
+            const float *const my_terms = terms + (el >> 4) * 64;       // lanes 16 e .. 16 e + 15 add up event e of a batch
+            // An event = one coefficient recomputed in the reference's own order (dct.c:72-93): lane j forms term j = x * 8 + y, the 64
+            // terms go to LDS, and the ordered sum is 64 dependent adds that EVERY lane executes.  Up to four events share those
+            // adds: each sixteen lanes read another event's terms (Q=90 has 1-2 events per tile, the adds were 60 % of an event).
+            // The values land in ONE register (the flagged lane's), and go into n[] behind the loop in straight-line code: a loop
+            // that updates n[st] itself makes the register allocator keep a second copy of all 32 values and move it back and forth
+            // per event (90 of the 230 instructions an event cost in round 2).  A round handles the LOWEST flagged site of every
+            // lane; a lane with two flagged sites (rare) makes a second round.
+            do {
+                const uint32_t low = flagbits & (0u - flagbits);
+                int fixval = 0;
+                unsigned long long todo = fm;
+                while (todo) {
+                    float sc = 0.0f, qs = 1.0f;
+                    unsigned long long me[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        me[e] = 0ull;
+                        if (todo) {                                 // (uniform)
+                            const int fl = __ffsll((long long)todo) - 1;
+                            todo &= todo - 1;
+                            const int st = __ffs(__builtin_amdgcn_readlane((int)low, fl)) - 1;
+                            const int z = 16 * (st >> 3) + 8 * (fl >> 5) + (st & 7);
+                            const int k = __builtin_amdgcn_readfirstlane((int)s_zz[z]), u = k >> 3, v = k & 7;
+                            const uint32_t pw = pix_lane[(fl & 31) * 4];
+                            const float pix = (float)__builtin_bit_cast(_Float16, (uint16_t)((el & 1) ? pw >> 16 : pw));
+                            const float cx = s_cos[u * 8 + (el >> 3)];     // COS_LUT[x][u]
+                            const float cy = s_cos[v * 8 + (el & 7)];      // COS_LUT[y][v]
+                            terms[e * 64 + el] = __fmul_rn(__fmul_rn(pix, cx), cy);             // dct.c:84
+                            const bool mine = (el >> 4) == e;
+                            sc = mine ? ref_scale(u, v) : sc;
+                            qs = mine ? s_qstep[z] : qs;
+                            me[e] = 1ull << fl;
+                            ++nexact;
+                            if (kTaps && el == fl) exact_mask |= 1ull << k;
+                        }
+                    }
+                    float sum = 0.0f;                               // dct.c:68
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float4 a = *reinterpret_cast<const float4 *>(&my_terms[8 * c]);
+                        const float4 b4 = *reinterpret_cast<const float4 *>(&my_terms[8 * c + 4]);
+                        sum = __fadd_rn(sum, a.x); sum = __fadd_rn(sum, a.y); sum = __fadd_rn(sum, a.z); sum = __fadd_rn(sum, a.w);
+                        sum = __fadd_rn(sum, b4.x); sum = __fadd_rn(sum, b4.y); sum = __fadd_rn(sum, b4.z); sum = __fadd_rn(sum, b4.w);
+                    }
+                    const int val = ref_quantise(__fmul_rn(sc, sum), qs);          // dct.c:93, quantization.c:34-36 (lanes of an unused quarter: anything)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int vtmp;
+                        const int ve = __builtin_amdgcn_readlane(val, 16 * e);
+                        asm volatile("v_mov_b32 %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, %3" : "+v"(fixval), "=&v"(vtmp) : "s"(ve), "s"(me[e]));
                     }
                 }
-            }
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    if (__ballot((low >> (8 * G)) & 0xFFu) == 0ull) continue;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {               // (asm: the compiler's version is and + compare + wait state + select)
+                        int m;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(low), "n"(8 * G + j));
+                        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(n[8 * G + j]) : "v"(m), "v"(fixval));
+                    }
+                }
+                flagbits ^= low;
+                fm = __ballot(flagbits != 0u);
+            } while (__builtin_expect(fm != 0ull, 0));
         }
         if (kTaps && active) {
             const size_t blk = (size_t)by * im.blocks_w + bx;

@@ -5,7 +5,7 @@
 // rounding as the reference's  roundf(F[u][v] / q)  (natural_c/src/core/dct.c:63-96, quantization.c:34-36) only when z is
 // further than delta from a rounding tie.  delta bounds |z_fast - r_ref| rigorously:
 //
-//   delta = (K/q) * (E_ref + E_mfma + E_split) + 4u (zmax + 1)
+//   delta = (K/q) * (E_ref + E_mfma + E_split) + 4u (zmax + 1)          (per zigzag position: q, K and the LUT weights differ)
 //
 //   E_ref    reference evaluation error: two roundings per product, one per sequential add, worst case over |p| <= 128
 //            with the actual |COS_LUT products| as weights
@@ -233,19 +233,24 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
         mt->qstep[z] = (float)table[k];
         if (delta_out) delta_out[k] = delta;
     }
-    mt->bias = (float)(0.5 + dmax * 1.001 + 1.0e-7);
-    const double db = (double)mt->bias - 0.5;
-    for (int z = 0; z < 64; ++z) mt->qthr[z] = (float)(db + delta_z[z] * 1.001 + 1.0e-7);
+    // One bias PER POSITION: zc = z + 0.5 + b_z with b_z >= delta_z, flagged when fract(zc) <= 2 b_z, i.e. z within b_z of a tie on
+    // either side.  (Rounds 1-2 used one bias for all positions, 0.5 + max delta: the band below a tie was then max delta wide
+    // everywhere -- 3.5 x the mean delta, 2.3 x the exact-order events of this layout.)  2 b - 1 is exact in float32 for b in [0.5, 1).
+    (void)dmax;
+    for (int z = 0; z < 64; ++z) {
+        mt->bias[z] = (float)(0.5 + delta_z[z] * 1.001 + 1.0e-7);
+        mt->qthr[z] = 2.0f * mt->bias[z] - 1.0f;
+    }
     if (!split_ok)                                          // cannot happen with the reference's LUT; if it did, EVERY coefficient takes the exact-order path
-        for (int z = 0; z < 64; ++z) mt->qthr[z] = 2.0f;
-    // zero threshold of a group: qthr < fl(a * qmul + bias) < 1 (i.e. floor = 0, not flagged) for every |a| below it;
+        for (int z = 0; z < 64; ++z) { mt->bias[z] = 1.5f; mt->qthr[z] = 2.0f; }      // (fract <= 2 always; the group thresholds come out negative: no group is skipped)
+    // zero threshold of a group: qthr_z < fl(a * qmul_z + bias_z) < 1 (i.e. floor = 0, not flagged) for every |a| below it;
     // the 2^-18 relative margin covers the single rounding of the kernel's fma
     for (int g = 0; g < 4; ++g)
         for (int h = 0; h < 2; ++h) {
             double t = 1.0e30;
             for (int j = 0; j < 8; ++j) {
                 const int z = 16 * g + 8 * h + j;
-                const double up = 1.0 - (double)mt->bias, dn = (double)mt->bias - (double)mt->qthr[z];
+                const double up = 1.0 - (double)mt->bias[z], dn = (double)mt->bias[z] - (double)mt->qthr[z];
                 t = std::fmin(t, std::fmin(up, dn) / (double)mt->qmul[z]);
             }
             float fmax = 0.0f;

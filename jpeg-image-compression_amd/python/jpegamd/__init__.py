@@ -123,12 +123,12 @@ SEG_META_WORDS = int(lib.jpegamd_segment_meta_words())      # metadata words per
 
 
 def mfma_consts(quality: int = 50):
-    """Constants of the matrix-pipe kernel: qmul/qthr float32[64] by zigzag position, bias, delta float64[64] by raster k."""
+    """Constants of the matrix-pipe kernel: qmul/qthr/bias float32[64] by zigzag position, delta float64[64] by raster k."""
     import numpy as np
     qmul, qthr = np.zeros(64, np.float32), np.zeros(64, np.float32)
-    bias, delta = np.zeros(1, np.float32), np.zeros(64, np.float64)
+    bias, delta = np.zeros(64, np.float32), np.zeros(64, np.float64)
     lib.jpegamd_debug_mfma_consts(quality, qmul.ctypes.data, qthr.ctypes.data, bias.ctypes.data, delta.ctypes.data)
-    return dict(qmul=qmul, qthr=qthr, bias=float(bias[0]), delta=delta)
+    return dict(qmul=qmul, qthr=qthr, bias=bias, delta=delta)
 
 
 def group_thresholds(quality: int = 50):

@@ -96,7 +96,7 @@ def test_constants_derivation_is_reentrant(jpegamd):
     def work(q):
         for _ in range(40):
             c = jpegamd.mfma_consts(q)
-            if not (np.array_equal(c["qmul"], want[q]["qmul"]) and np.array_equal(c["qthr"], want[q]["qthr"]) and c["bias"] == want[q]["bias"]):
+            if not (np.array_equal(c["qmul"], want[q]["qmul"]) and np.array_equal(c["qthr"], want[q]["qthr"]) and np.array_equal(c["bias"], want[q]["bias"])):
                 bad.append(q)
     ts = [threading.Thread(target=work, args=(q,)) for q in (10, 90, 10, 90)]
     [t.start() for t in ts]
@@ -105,23 +105,52 @@ def test_constants_derivation_is_reentrant(jpegamd):
 
 
 def test_mfma_constants_are_on_the_safe_side(jpegamd, oracle):
-    """Matrix-pipe kernel: threshold >= (bias - 0.5) + delta for every coefficient, bias - 0.5 >= every delta, the
-    multiplier is K/q (the MFMA output is the plain LUT sum)."""
+    """Matrix-pipe kernel, per zigzag position: bias - 0.5 >= delta (the band on either side of a rounding tie), the flag threshold is
+    2 bias - 1 EXACTLY (the kernel derives it so, in float32) and not much wider than 2 delta; the multiplier is K/q (the MFMA output
+    is the plain LUT sum)."""
     zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
     for q in (50, 10, 90):
         c = jpegamd.mfma_consts(q)
         table = oracle.quant_table(q)
-        db = np.float64(np.float32(c["bias"])) - 0.5
         for z in range(64):
             k = zz[z]
-            assert db >= c["delta"][k] or z == 0
+            db = np.float64(np.float32(c["bias"][z])) - 0.5
+            assert db >= c["delta"][k]
+            assert np.float32(c["qthr"][z]) == np.float32(np.float32(2.0) * np.float32(c["bias"][z]) - np.float32(1.0))     # what fma(2, bias, -1) gives
+            assert np.float64(c["qthr"][z]) == 2.0 * db                      # ... which is exact
             assert np.float64(c["qthr"][z]) >= db + c["delta"][k]
+            assert np.float64(c["qthr"][z]) <= 2.01 * c["delta"][k] + 4e-7    # no wider than needed (one bias for all positions was 2.3 x as wide on average)
             u, v = divmod(k, 8)
             kk = np.float32(np.float32(np.float32(0.25) * (np.float32(0.707107) if u == 0 else np.float32(1))) * (np.float32(0.707107) if v == 0 else np.float32(1)))
             assert abs(float(c["qmul"][z]) * 2048.0 - float(kk) / float(table[k])) <= 1e-7 * float(kk)     # kMfmaScale = 2^11
             assert float(c["qthr"][z]) < 0.01                                # (2.0 would mean: the integer split failed, everything is flagged)
         assert 1e-5 < c["delta"][1:].max() < 5e-3
+
+
+def test_dc_closed_form(jpegamd):
+    """The kernel never recomputes a DC coefficient: it quantises |S| (S = the block's centred pixel sum, an exact integer) as
+    floor(|S| K/q + 0.5 + delta) and puts the sign back.  That rests on two facts, both checked here by exhaustion:
+      (a) the reference's DC value -- fl(scale * S) with scale = fl(fl(0.25 * 0.707107) * 0.707107) (dct.c:87-93), a correctly
+          rounded float32 division by q and roundf (quantization.c:34-36) -- equals sign(S) * floor((|S| + 4 q) / (8 q)) for EVERY
+          sum of 64 values in [-128, 127] and EVERY q in 1 .. 255 (the scale lies above 1/8: all ties go away from zero);
+      (b) the kernel's own evaluation, one float32 fma of 2048 |S| with the stored multiplier and bias of zigzag 0, then floor,
+          gives that value for every S at every quality 1 .. 100, with a margin far above a float32 step."""
+    f32, f64 = np.float32, np.float64
+    S = np.arange(-128 * 64, 127 * 64 + 1, dtype=np.int64)
+    scale = f32(f32(f32(0.25) * f32(0.707107)) * f32(0.707107))
+    for q in range(1, 256):
+        z = ((scale * S.astype(f32)).astype(f32) / f32(q)).astype(f32).astype(f64)          # float32 products / quotients, correctly rounded
+        ref = (np.sign(z) * np.floor(np.abs(z) + 0.5)).astype(np.int64)                     # roundf: half away from zero (exact in float64)
+        assert np.array_equal(ref, np.sign(S) * ((np.abs(S) + 4 * q) // (8 * q))), q
+    for quality in range(1, 101):
+        c = jpegamd.mfma_consts(quality)
+        q0 = int(jpegamd.quant_table(quality)[0])
+        zc64 = np.abs(S).astype(f64) * 2048.0 * f64(c["qmul"][0]) + f64(f32(c["bias"][0]))  # 24 x 24 bits: the product is exact in float64
+        n = np.floor(zc64.astype(f32)).astype(np.int64) * np.sign(S)
+        assert np.array_equal(n, np.sign(S) * ((np.abs(S) + 4 * q0) // (8 * q0))), quality
+        margin = np.abs(zc64 - np.rint(zc64)).min()                                          # the ties sit delta above an integer
+        assert margin > 4 * np.spacing(f32(zc64.max())) and margin > 0.9 * (f64(f32(c["bias"][0])) - 0.5), quality
 
 
 def test_group_zero_thresholds_are_safe(jpegamd):
@@ -132,7 +161,6 @@ def test_group_zero_thresholds_are_safe(jpegamd):
     for q in (50, 10, 90, 1, 100):
         c = jpegamd.mfma_consts(q)
         thr = jpegamd.group_thresholds(q)
-        bias = f32(c["bias"])
         assert (thr > 0).all()
         for g in range(4):
             for h in range(2):
@@ -140,9 +168,10 @@ def test_group_zero_thresholds_are_safe(jpegamd):
                 for j in range(8):
                     z = 16 * g + 8 * h + j
                     for a in (t, -t, np.nextafter(t, f32(0)), -np.nextafter(t, f32(0))):
-                        zc = f32(np.float64(a) * np.float64(c["qmul"][z]) + np.float64(bias))      # one rounding, like v_fma_f32
+                        zc = f32(np.float64(a) * np.float64(c["qmul"][z]) + np.float64(f32(c["bias"][z])))      # one rounding, like v_fma_f32
                         assert f32(c["qthr"][z]) < zc < f32(1.0), (q, g, h, j, float(a), float(zc))
-        assert thr[0].min() <= thr[3].max()                         # coarser quantisation higher up: larger zero zone
+        if 10 <= q <= 90:
+            assert thr[0].min() <= thr[3].max()                     # coarser quantisation higher up: larger zero zone (Q=1 / 100: every step is 255 / 1)
 
 
 def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
@@ -196,7 +225,6 @@ def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
     for q in (50, 90):
         c = jpegamd.mfma_consts(q)
         table = oracle.quant_table(q).astype(f32)
-        bias = f32(c["bias"])
         for order in ("forward", "reverse", "pairwise"):
             chains = [chain(t, order) for t in terms]
             for got, want in zip(chains, exact):
@@ -205,7 +233,7 @@ def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
             unflagged = 0
             for z in range(64):
                 k = zz[z]
-                zc = (acc[:, k].astype(f64) * f64(c["qmul"][z]) + f64(bias)).astype(f32)      # v_fma_f32: one rounding
+                zc = (acc[:, k].astype(f64) * f64(c["qmul"][z]) + f64(f32(c["bias"][z]))).astype(f32)      # v_fma_f32: one rounding
                 n = np.floor(zc).astype(np.int64)
                 flagged = (zc - np.floor(zc)) <= f32(c["qthr"][z])
                 want = np.array([int(np.float32(np.round(np.float32(r) / table[k]))) if abs(np.float32(r) / table[k]) % 1 != 0.5
