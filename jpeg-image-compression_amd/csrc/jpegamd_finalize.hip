@@ -21,6 +21,7 @@
 namespace jpegamd {
 
 constexpr int kFinWaves = 16;                                  // segments per workgroup
+constexpr int kFinStagePieces = 130;                           // 16-byte pieces of a wave's staging strip
 
 __device__ __forceinline__ uint32_t fin_bits_at(const uint32_t *__restrict__ w, uint32_t pos, int nbits /*1..8*/) {
     const uint32_t i = pos >> 5, sh = pos & 31u;
@@ -97,6 +98,7 @@ struct FinalizeView {
 
 __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs args) {
     __shared__ uint32_t s_wbits[2][kFinWaves], s_wff[2][kFinWaves];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kFinWaves][4 * kFinStagePieces];   // per wave: the 0xFF branch's staging strip (15 + 2 x 1024 bytes at most)
     static_assert(kFinWaves == 16, "the waves' totals are scanned in one DPP row");
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tid = (int)threadIdx.x;
     // A batch: workgroup -> (image, chunk inside the image); everything below works on that image alone (bit offsets, byte
@@ -229,7 +231,11 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
     const uint64_t base = (uint64_t)a.prefix_len + (b0 >> 3) + chunk_ff0 + ff_in;
     uint32_t running = 0;
     bool overflow = false;
+#ifdef JPEGAMD_FIN_NOFF          // timing-only build: every segment takes the no-0xFF path (wrong bytes behind the first 0xFF)
+    if (true) {
+#else
     if (my_ff == 0u) {
+#endif
         // No 0xFF among the owned bytes (nearly every segment): the bytes land contiguously, so the middle goes out as ALIGNED
         // 16-byte pieces -- lane k builds output dwords 4 k .. 4 k + 3 straight from the bit string: five string words, four
         // funnel shifts -- and at most 15 + 15 bytes at the two ends.  (One dword per lane cost 45 instructions per 64 dwords.)
@@ -267,33 +273,95 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
         } else {
             overflow = true;
         }
+    } else if (base + nown + my_ff > a.out_capacity) {
+        overflow = true;
     } else {
-        const uint32_t ndw = (nown + 3u) >> 2;                                      // four owned bytes per lane
-        for (uint32_t i0 = 0; i0 < ndw; i0 += 64) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            const bool valid = i < ndw;
-            uint32_t w = 0;
-            if (valid) w = __builtin_amdgcn_alignbit(i ? words[i - 1] : leadbits, words[i], lead);   // ({prev, cur} >> lead): lead = 0 gives cur
-            const uint32_t nv = valid ? min(4u, nown - 4u * i) : 0u;                // 1..4 owned bytes in this dword, from the top
-            const uint32_t m = valid ? (fin_ff_mask(w) & (0x01010101u << (8u * (4u - nv)))) : 0u;
-            const uint32_t c = (uint32_t)__popc(m);
-            const uint32_t incl = wave_incl_scan_u32(c);
-            uint64_t pos = base + 4ull * i + running + (incl - c);
-            if (valid) {
-                if (pos + nv + c <= a.out_capacity) {
+        // 0xFF among the owned bytes (one byte in ~300 of photo-like content: nearly every segment of 16 tiles has some).  Sixteen
+        // owned bytes per lane and pass, built from the bit string as in the branch above; a wave prefix sum over the lanes' 0xFF
+        // counts says where each lane's bytes go; the lane writes them one by one into a ZEROED staging strip in LDS -- the stuffed
+        // 0x00 behind an 0xFF (huffman.c:29-31) is simply left out -- and the strip leaves as aligned 16-byte pieces.  Strip
+        // offset == output address mod 16: what does not fill a piece stays as the head of the next pass.  (Round 2 stored every
+        // byte to HBM by itself, four bytes per lane and pass, behind 64-bit address arithmetic and a branch per byte: ~600
+        // instructions per KiB against ~120, and k_finalize at 2.7 x the duration the no-0xFF branch would have.)
+        typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        uint8_t *const stage = reinterpret_cast<uint8_t *>(&s_stage[wave][0]);
+        u32x4 *const stage16 = reinterpret_cast<u32x4 *>(&s_stage[wave][0]);
+        const u32x4 zero4 = {0u, 0u, 0u, 0u};
+        for (int p = lane; p < kFinStagePieces; p += 64) stage16[p] = zero4;
+        const uint32_t fill0 = (uint32_t)((uintptr_t)(a.out + base) & 15u);         // the bytes in front of it in the first piece belong to earlier segments
+        uint32_t fill = fill0;
+        uint8_t *gdst = a.out + base - fill0;                                       // where strip byte 0 goes: 16-byte aligned
+        bool first = true;
+        const uint32_t sh = (32u - lead) & 31u;                                     // a lane's 16 bytes start `lead` bits in front of a word boundary
+        const auto request = [&](uint32_t idx, u32x4a &x, uint32_t &x4) {           // string words 4 idx - (lead ? 1 : 0) .. + 4 of 16-byte group idx
+            if (16u * idx < nown) {
+                const int wi = 4 * (int)idx - (lead ? 1 : 0), wl = max(wi, 0);
+                x = *reinterpret_cast<const u32x4a *>(words + wl);
+                x4 = words[wl + 4];
+            }
+        };
+        u32x4a nx = {0u, 0u, 0u, 0u};
+        uint32_t nx4 = 0;
+        request((uint32_t)lane, nx, nx4);
+        for (uint32_t done = 0; done < nown; done += 1024u) {                       // (the next pass's words are requested ahead of this pass's work)
+            const uint32_t idx = (done >> 4) + (uint32_t)lane;
+            const u32x4a x = nx;
+            const uint32_t x4 = nx4;
+            request(idx + 64u, nx, nx4);
+            const bool borrow = idx == 0u && lead != 0u;
+            const uint32_t v0 = borrow ? leadbits : x[0], v1 = borrow ? x[0] : x[1], v2 = borrow ? x[1] : x[2], v3 = borrow ? x[2] : x[3],
+                           v4 = borrow ? x[3] : x4;
+            uint32_t v[4];
+            v[0] = sh ? __builtin_amdgcn_alignbit(v0, v1, 32u - sh) : v0;
+            v[1] = sh ? __builtin_amdgcn_alignbit(v1, v2, 32u - sh) : v1;
+            v[2] = sh ? __builtin_amdgcn_alignbit(v2, v3, 32u - sh) : v2;
+            v[3] = sh ? __builtin_amdgcn_alignbit(v3, v4, 32u - sh) : v3;
+            const uint32_t left = nown - done;                                      // owned bytes from this pass on
+            if (left < 1024u) {                                                     // (uniform) the last pass: bytes beyond the owned ones count as zeros
+                const int nvl = (int)left - 16 * lane;                              // this lane's owned bytes: <= 0 none, >= 16 all
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {                              // byte k from the top (stream order)
-                        if (k < nv) {
-                            a.out[pos++] = (uint8_t)(w >> (24u - 8u * k));
-                            if (m & (1u << (24u - 8u * k))) a.out[pos++] = 0x00;
-                        }
-                    }
-                } else {
-                    overflow = true;
+                for (int k = 0; k < 4; ++k) {
+                    const int kb = min(max(nvl - 4 * k, 0), 4);
+                    v[k] = kb ? v[k] & (0xFFFFFFFFu << (8 * (4 - kb))) : 0u;
                 }
             }
-            running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t m[4], c = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k] = ((v[k] & 0x7F7F7F7Fu) + 0x01010101u) & v[k] & 0x80808080u;   // bit 7 of a byte: the byte is 0xFF (0x7F + 1 carries into bit 7 only)
+                c += (uint32_t)__popc(m[k]);
+            }
+            const uint32_t incl = wave_incl_scan_u32(c);
+            const uint32_t nfill = fill + min(left, 1024u) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);     // <= 15 + 2048
+            // byte t of the lane goes to (strip offset of the lane) + t + (0xFF bytes among its bytes in front of t); bytes beyond the owned
+            // ones are zeros that land beyond the data, where the strip is zero anyway
+            uint32_t at = fill + 16u * (uint32_t)lane + incl - c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                stage[at] = (uint8_t)(v[k] >> 24); at += 1u + (m[k] >> 31);
+                stage[at] = (uint8_t)(v[k] >> 16); at += 1u + ((m[k] >> 23) & 1u);
+                stage[at] = (uint8_t)(v[k] >> 8);  at += 1u + ((m[k] >> 15) & 1u);
+                stage[at] = (uint8_t)v[k];         at += 1u + ((m[k] >> 7) & 1u);
+            }
+            const uint32_t npieces = nfill >> 4;                                    // complete pieces: <= 128
+            const u32x4 rest = stage16[npieces];                                    // (one address for the wave) the incomplete piece
+            if (first && fill0 && (uint32_t)lane >= fill0 && (uint32_t)lane < min(16u, nfill)) gdst[lane] = stage[lane];   // the segment's first piece: its own bytes one by one
+            for (uint32_t p = (uint32_t)lane; p < npieces; p += 64u) {
+                const u32x4 piece = stage16[p];
+                if (!(first && fill0 && p == 0u)) *reinterpret_cast<u32x4 *>(gdst + 16u * p) = piece;
+                stage16[p] = zero4;
+            }
+            if (lane == 0) {
+                stage16[npieces] = zero4;
+                stage16[0] = rest;
+            }
+            gdst += 16u * npieces;
+            fill = nfill & 15u;
+            first = first && npieces == 0u;
         }
+        if ((uint32_t)lane < fill && !(first && (uint32_t)lane < fill0)) gdst[lane] = stage[lane];     // what is left of the last piece
+        running = my_ff;
     }
     if (__any(overflow) && lane == 0) atomicOr(&a.stats->status, 1u);
 
