@@ -549,6 +549,80 @@ def test_one_image_sharded_by_block_rows(jpegamd, oracle, dev):
 
 
 @pytest.mark.gpu
+def _segment_meta(bits: np.ndarray, word_off: int):
+    """Metadata of one unstuffed segment string as k_segment_merge leaves it (jpegamd_export_segments' 12 words): bit count, word
+    offset, (first 8 bits << 8) | last 7 bits, and for each byte phase p the 0xFF bytes lying WHOLLY inside the string when its
+    first bit sits at bit p of a byte (16 bits each)."""
+    n = len(bits)
+    first8 = int("".join(map(str, np.concatenate([bits[:8], np.zeros(max(0, 8 - n), np.uint8)]))), 2)
+    last7 = int("".join(map(str, bits[-7:])), 2) if n else 0
+    ones8 = np.zeros(max(n - 7, 0), bool)
+    if n >= 8:
+        c = np.concatenate([[0], np.cumsum(bits, dtype=np.int64)])
+        ones8 = (c[8:] - c[:-8]) == 8                                  # ones8[o]: the 8 bits from offset o are all ones
+    ff = [int(ones8[(8 - ph) % 8::8].sum()) for ph in range(8)]
+    m = np.zeros(12, np.uint32)
+    m[0], m[1], m[2] = n, word_off, (first8 << 8) | last7
+    for ph in range(8):
+        m[8 + ph // 2] |= np.uint32(ff[ph] << (16 * (ph & 1)))
+    return m
+
+
+def test_finalize_over_synthetic_segments(jpegamd, dev):
+    """k_finalize alone, fed through the segment exchange (jpegamd_import_segments) with bit strings no picture produces on
+    demand: dense in ones (every byte 0xFF, runs of 0xFF across segment borders), lengths around the kernel's pass sizes
+    (1024 owned bytes per pass, 16-byte output pieces), segments that end on and off byte boundaries, long segments, a last
+    segment that leaves 1 .. 7 bits for the zero-padded flush.  Expected bytes: the concatenated bits, padded with zeros
+    to a byte, 0x00 behind every 0xFF (huffman.c:26-81) -- computed here in numpy."""
+    rng = np.random.default_rng(77)
+    W = 2048                                                           # 256 blocks per row: one 8-tile segment per block row
+    lens = [16, 24, 23, 8191, 8192, 8193, 8200, 8184 + 5, 16384, 16390, 3 * 8192 + 1, 40001, 127, 128, 129, 64, 9000, 15, 8, 100000, 8 * 1023, 8 * 1024,
+            8 * 1025, 8 * 2047 + 3, 33, 7777, 8 * 16, 8 * 16 + 1, 8 * 15, 250000, 17, 4095 * 8, 4097 * 8, 61, 12345, 8 * 3000 + 4]
+    for case, dens in enumerate((0.5, 0.9, 0.995, 1.0, 0.0)):
+        lens_c = lens if case % 2 == 0 else lens[::-1]
+        H = 8 * len(lens_c)
+        strings = []
+        for n in lens_c:
+            b = (rng.random(n) < dens).astype(np.uint8)
+            if n < 8:
+                b[:] = 0
+            strings.append(b)
+        words, metas, off = [], [], 0
+        for b in strings:
+            nw = (len(b) + 31) // 32
+            padded = np.concatenate([b, np.zeros(nw * 32 - len(b), np.uint8)])
+            w = np.packbits(padded).view(">u4").astype(np.uint32)
+            metas.append(_segment_meta(b, off))
+            words.append(w)
+            off += nw
+        dense = torch.from_numpy(np.concatenate(words).view(np.int32).copy()).to(dev)
+        meta = torch.from_numpy(np.concatenate(metas).view(np.int32).copy()).to(dev)
+        allbits = np.concatenate(strings)
+        padded = np.concatenate([allbits, np.zeros((-len(allbits)) % 8, np.uint8)])
+        raw = np.packbits(padded)
+        want = bytearray()
+        for x in raw.tobytes():
+            want.append(x)
+            if x == 0xFF:
+                want.append(0)
+        px = torch.zeros(64, dtype=torch.uint8, device=dev)           # never read: k_finalize works on the imported segments alone
+        img = jpegamd.Encoder.image(px.data_ptr(), W, H, 3 * W, False, jpegamd.ORDER_BGR, 0)
+        enc = jpegamd.Encoder(W, H)
+        for shift in (0, 5):                                           # output buffers at two alignments
+            cap = len(want) + 64
+            out = torch.full((cap + 16,), 0xAA, dtype=torch.uint8, device=dev)
+            size = torch.zeros(1, dtype=torch.int64, device=dev)
+            enc.import_segments(img, 0, len(strings), dense.data_ptr(), meta.data_ptr(), 0)
+            enc.finalize_async(img, out.data_ptr() + shift, cap, size.data_ptr(), False, 0)
+            enc.finish()
+            n = int(size.item())
+            got = bytes(out[shift:shift + n].cpu().numpy())
+            assert n == len(want) and got == bytes(want), (case, dens, shift, n, len(want),
+                                                           next((i for i, (x, y) in enumerate(zip(got, want)) if x != y), None))
+            assert bytes(out[shift + n:shift + n + 8].cpu().numpy()) == b"\xaa" * 8 and (shift == 0 or bytes(out[:shift].cpu().numpy()) == b"\xaa" * shift)
+
+
+@pytest.mark.gpu
 def test_sharded_image_encoder_single_rank(jpegamd, oracle, dev):
     """jpegamd.sharding.ShardedImageEncoder without a process group: rows -> export -> finalize on one context."""
     from jpegamd.sharding import ShardedImageEncoder
