@@ -171,9 +171,10 @@ int32_t jpegamd_debug_quant_table(int32_t quality, uint8_t *table);
 
 /* Constants of the fast quantiser: qmul, qthr, bias float[64] by ZIGZAG position; the rigorous guard band delta, double[64], by raster k. */
 int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, float *bias, double *delta);
-/* Zero thresholds of the split pipeline's coefficient groups ([group 0..3][lane half 0..1], group G of half h =
- * zigzag 16G+8h .. +7): a tile whose |LUT sums| all stay below them skips that group's quantiser entirely. */
-int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr);
+/* Zero thresholds of the coefficient groups ([group 0..3][lane half 0..1], group G of half h = zigzag 16G+8h .. +7): a tile
+ * whose hi-chain LUT sums all stay below grp_thr skips that group's quantiser entirely; lo_bound (may be NULL) is the largest
+ * magnitude the lo chain can add to a site of the group -- grp_thr has it taken off. */
+int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr, float *lo_bound);
 /* The six-decimal cosine table the kernels multiply with, [x][u] (natural_c/src/core/dct.c:9-18), for host-side emulations. */
 int32_t jpegamd_debug_cos_lut(float *lut);
 

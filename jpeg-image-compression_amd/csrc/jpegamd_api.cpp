@@ -97,7 +97,7 @@ extern "C" int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float
     return JPEGAMD_OK;
 }
 
-extern "C" int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr /*[4 groups][2 lane halves]*/) {
+extern "C" int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr /*[4 groups][2 lane halves]*/, float *lo_bound /*same shape, may be NULL*/) {
     uint8_t t[64];
     if (!grp_thr) return JPEGAMD_ERR_ARG;
     MfmaTables *mt = new (std::nothrow) MfmaTables;
@@ -105,6 +105,7 @@ extern "C" int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_th
     quant_table_for_quality(quality, t);
     derive_mfma_tables(t, mt, nullptr);
     std::memcpy(grp_thr, mt->grp_thr, sizeof(mt->grp_thr));
+    if (lo_bound) std::memcpy(lo_bound, mt->lo_bound, sizeof(mt->lo_bound));
     delete mt;
     return JPEGAMD_OK;
 }

@@ -79,7 +79,9 @@ struct MfmaTables {
     float qthr[64];                // flag threshold 2 (bias_z - 0.5), exactly (the kernel derives it as fma(2, bias_z, -1))
     float qstep[64];               // (float) q, by zigzag position
     float bias[64];                // by zigzag position: 0.5 + delta_z (with margin) -- a band of delta_z on EITHER side of a rounding tie
-    float grp_thr[8];              // [group G][lane half h]: |MFMA output| below it => zigzag 16G+8h .. +7 all quantise to an unflagged 0
+    float grp_thr[8];              // [group G][lane half h]: |hi-chain output| below it in every site => zigzag 16G+8h .. +7 all quantise to an unflagged 0
+                                   // (the lo chain's largest possible contribution, lo_bound, is taken off: the test runs ahead of the add that joins the chains)
+    float lo_bound[8];             // [group G][lane half h]: max over the sites of |lo-chain output|, in accumulator units
     float flag_thr[8];             // [group G][lane half h]: max qthr over zigzag 16G+8h .. +7
 };
 

@@ -440,16 +440,17 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
             gact[G] = true;
-            float a8[8];                                            // the group's LUT sums (times kMfmaScale)
+            if (G > 0) {                                            // |sum| below the group's zero threshold in every lane?  Tested on the hi chain
+                                                                    // alone (the threshold has the lo chain's bound taken off): no join adds for a skipped group
+                float m = fmaxf(fabsf(acc[1][(8 * G) >> 4][(8 * G) & 15]), fabsf(acc[1][(8 * G + 1) >> 4][(8 * G + 1) & 15]));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a8[j] = JPEGAMD_ACC(8 * G + j);
-            if (G > 0) {                                            // |sum| below the group's zero threshold in every lane?
-                float m = fmaxf(fabsf(a8[0]), fabsf(a8[1]));
-#pragma unroll
-                for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(a8[j]));
+                for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(acc[1][(8 * G + j) >> 4][(8 * G + j) & 15]));
                 gact[G] = __ballot(m >= q_lane[128 + G]) != 0ull;
             }
             if (gact[G]) {
+                float a8[8];                                        // the group's LUT sums (times kMfmaScale)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = JPEGAMD_ACC(8 * G + j);
                 float fr[8];
                 // DC (zigzag 0: site 0 of lanes h == 0).  Its LUT sum S is an exact integer and the reference's value has a closed form,
                 // sign(S) floor((|S| + 4 q) / 8 q): the scale 0.25 * 0.707107^2 lies 6.2e-7 ABOVE 1/8, which pushes the ties S = 4 q (2 m + 1)
@@ -592,7 +593,12 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             int vv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) vv[j] = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];   // DC is not an AC symbol
-            const uint32_t c = count_ne8(0u, vv);
+            // non-zero values of the group: min(|v| as unsigned, 1) summed by three-operand adds -- 12 instructions against the 16 of a
+            // compare / add-with-carry pair per site
+            uint32_t f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm("v_min_u32_e32 %0, 1, %1" : "=v"(f[j]) : "v"(vv[j]));      // (asm: the compiler turns min(x, 1) back into compare + select + wait state)
+            const uint32_t c = (f[0] + f[1] + f[2]) + (f[3] + f[4] + f[5]) + (f[6] + f[7]);
             cnt += c << (8 * G);
         }
         cnt += eob ? (1u << 24) : 0u;

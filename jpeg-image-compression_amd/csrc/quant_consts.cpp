@@ -183,7 +183,7 @@ double from_f16(uint16_t b) {
 void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_out[64]) {
     std::memset(mt, 0, sizeof(*mt));
     uint16_t *af = reinterpret_cast<uint16_t *>(mt->afrag);
-    double delta_z[64];
+    double delta_z[64], lo_abs[64];
     double dmax = 0;
     bool split_ok = true;
     const double S = (double)kMfmaScale;
@@ -221,6 +221,7 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
         // summation order: |pixel| * sum |term| bounds them all.  What is left of the matrix pipe is the ONE rounding of the add
         // that joins the chains, relative to |S| <= kPmax * wsum.
         if (kPmax * hi_units > 16777216.0 || kPmax * lo_units > 16777216.0) split_ok = false;      // (integers up to 2^24 inclusive are float32 values)
+        lo_abs[z] = kPmax * lo_units / 2048.0;              // |lo-chain output| <= this (the terms are stored as lo 2^-11)
         const double e_mfma = kU * kPmax * wsum * 1.0001;
         const float cu = u == 0 ? 0.707107f : 1.0f, cv = v == 0 ? 0.707107f : 1.0f;
         const double K = (double)((0.25f * cu) * cv);
@@ -243,7 +244,7 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
     }
     if (!split_ok)                                          // cannot happen with the reference's LUT; if it did, EVERY coefficient takes the exact-order path
         for (int z = 0; z < 64; ++z) { mt->bias[z] = 1.5f; mt->qthr[z] = 2.0f; }      // (fract <= 2 always; the group thresholds come out negative: no group is skipped)
-    // zero threshold of a group: qthr_z < fl(a * qmul_z + bias_z) < 1 (i.e. floor = 0, not flagged) for every |a| below it;
+    // zero threshold of a group: qthr_z < fl(a * qmul_z + bias_z) < 1 (i.e. floor = 0, not flagged) for every |a| below t;
     // the 2^-18 relative margin covers the single rounding of the kernel's fma
     for (int g = 0; g < 4; ++g)
         for (int h = 0; h < 2; ++h) {
@@ -256,8 +257,14 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
             float fmax = 0.0f;
             for (int j = 0; j < 8; ++j) fmax = std::fmax(fmax, mt->qthr[16 * g + 8 * h + j]);
             mt->flag_thr[2 * g + h] = fmax;
-            mt->grp_thr[2 * g + h] = (float)(t * (1.0 - 1.0 / 262144.0));
-            if ((double)mt->grp_thr[2 * g + h] > t * (1.0 - 1.0 / 524288.0)) mt->grp_thr[2 * g + h] = std::nextafterf(mt->grp_thr[2 * g + h], 0.0f);
+            // The kernel tests the hi chain alone (the add that joins the chains is then spent on active groups only):
+            // |hi| < thr and |lo| <= lo_bound give |fl(hi + lo)| <= (thr + lo_bound) (1 + 2^-24) < t.
+            double lob = 0;
+            for (int j = 0; j < 8; ++j) lob = std::fmax(lob, lo_abs[16 * g + 8 * h + j]);
+            mt->lo_bound[2 * g + h] = (float)(lob * (1.0 + 1.0 / 1048576.0));
+            const double th = t * (1.0 - 1.0 / 262144.0) - (double)mt->lo_bound[2 * g + h] * (1.0 + 1.0 / 1048576.0);
+            mt->grp_thr[2 * g + h] = th > 0.0 ? (float)th : 0.0f;                  // (0: |hi| >= 0 always -- the group is never skipped)
+            if (th > 0.0 && (double)mt->grp_thr[2 * g + h] > th) mt->grp_thr[2 * g + h] = std::nextafterf(mt->grp_thr[2 * g + h], 0.0f);
         }
 }
 

@@ -78,7 +78,7 @@ def _load() -> C.CDLL:
         "jpegamd_debug_quant_table": (i32, [i32, vp]),
         "jpegamd_segment_meta_words": (i32, []),
         "jpegamd_debug_mfma_consts": (i32, [i32, vp, vp, vp, vp]),
-        "jpegamd_debug_group_thresholds": (i32, [i32, vp]),
+        "jpegamd_debug_group_thresholds": (i32, [i32, vp, vp]),
         "jpegamd_debug_cos_lut": (i32, [vp]),
         "JpegCompression_Init": (i32, []),
         "JpegCompression_DeInit": (i32, []),
@@ -131,12 +131,12 @@ def mfma_consts(quality: int = 50):
     return dict(qmul=qmul, qthr=qthr, bias=bias, delta=delta)
 
 
-def group_thresholds(quality: int = 50):
-    """float32 [4][2]: zero threshold of coefficient group G for lane half h (split pipeline)."""
+def group_thresholds(quality: int = 50, with_lo_bound: bool = False):
+    """float32 [4][2]: zero threshold of coefficient group G for lane half h, on the hi chain (with_lo_bound: and the lo chain's bound)."""
     import numpy as np
-    t = np.zeros(8, np.float32)
-    lib.jpegamd_debug_group_thresholds(quality, t.ctypes.data)
-    return t.reshape(4, 2)
+    t, lo = np.zeros(8, np.float32), np.zeros(8, np.float32)
+    lib.jpegamd_debug_group_thresholds(quality, t.ctypes.data, lo.ctypes.data)
+    return (t.reshape(4, 2), lo.reshape(4, 2)) if with_lo_bound else t.reshape(4, 2)
 
 
 def cos_lut():

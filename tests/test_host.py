@@ -154,17 +154,29 @@ def test_dc_closed_form(jpegamd):
 
 
 def test_group_zero_thresholds_are_safe(jpegamd):
-    """Skipping a coefficient group is only legal if EVERY |LUT sum| below the threshold quantises to an unflagged 0:
-    for each site of the group, in float32 exactly as the kernel evaluates it, fl(a * qmul + bias) must stay inside
-    (qthr, 1) for a = +-threshold (monotone in a), so floor() is 0 and fract() is above the flag threshold."""
+    """Skipping a coefficient group is only legal if EVERY LUT sum it can hide quantises to an unflagged 0.  The kernel tests the
+    hi accumulator chain alone, |hi| < thr in every site; the lo chain adds at most lo_bound, and the add that joins them rounds
+    once: |a| <= (thr + lo_bound)(1 + 2^-24).  For each site of the group, in float32 exactly as the kernel evaluates it,
+    fl(a * qmul + bias) must stay inside (qthr, 1) for a = +-that (monotone in a), so floor() is 0 and fract() is above the flag
+    threshold.  lo_bound itself is checked against the split of the LUT products."""
     f32 = np.float32
+    zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+    lut = jpegamd.cos_lut().astype(np.float64)
+    lo_true = np.zeros((4, 2))                                     # |lo-chain output| <= 128 x sum |lo term|, per group and lane half
+    for z in range(64):
+        u, v = divmod(zz[z], 8)
+        K = np.outer(lut[:, u], lut[:, v]).reshape(64)
+        lo = np.rint((K - np.rint(K * 2048.0) / 2048.0) * 4194304.0) / 2048.0
+        lo_true[z >> 4, (z >> 3) & 1] = max(lo_true[z >> 4, (z >> 3) & 1], 128.0 * np.abs(lo).sum())
     for q in (50, 10, 90, 1, 100):
         c = jpegamd.mfma_consts(q)
-        thr = jpegamd.group_thresholds(q)
-        assert (thr > 0).all()
+        thr, lob = jpegamd.group_thresholds(q, with_lo_bound=True)
+        assert (lob.astype(np.float64) >= lo_true).all()
+        assert (thr > 0).all() and (lob > 0).all() and (lob <= 4096.0 * 1.001).all()      # 64 terms x |p| <= 128 x |lo| <= 1024 / 2048
         for g in range(4):
             for h in range(2):
-                t = f32(thr[g, h])
+                t = f32((np.float64(thr[g, h]) + np.float64(lob[g, h])) * (1.0 + 2.0 ** -23))
                 for j in range(8):
                     z = 16 * g + 8 * h + j
                     for a in (t, -t, np.nextafter(t, f32(0)), -np.nextafter(t, f32(0))):
