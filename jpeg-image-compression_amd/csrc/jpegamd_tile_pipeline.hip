@@ -132,8 +132,9 @@ constexpr int kTileGroups = JPEGAMD_TILE_GROUPS;                 // ticket count
 constexpr int kWinWords = 256;                                   // bit window per wave in LDS: the tile's record (8 words) + 248 string words
 constexpr int kWinStr = kWinWords - kTileRecWords;
 constexpr int kPassItems = 128;                                  // items coded per pass: two per lane
+constexpr int kQuadMinItems = 384;                               // lists at least this long try four items per lane first
 static_assert(16 * 65 <= kStageItemCap, "half a tile's items (16 blocks) always fit the staging region");
-static_assert(kPassItems * (27 + 3 * (int)kZrlBits) / 32 + 4 <= kWinStr, "the window takes a whole pass, ZRLs included");
+static_assert(kPassItems * (27 + 3 * (int)kZrlBits) / 32 + 6 <= kWinStr && 2 * kPassItems * 27 / 32 + 6 <= kWinStr, "the window takes a whole pass, ZRLs included, and a four-item pass without");
 
 struct TileSched {            // division-free launch geometry, filled by launch_tile_transform
     int32_t grp_shift;        // workgroups form 1 << grp_shift ticket groups (blockIdx & mask)
@@ -183,16 +184,38 @@ __device__ __forceinline__ void append_group_lds(uint32_t &addr, int (&v)[8], ui
 //   size            31 - v_ffbh_i32(2 w), -1 -> 0         rle.c:9-22 without the abs / zero special cases
 //   row             gap to the predecessor = run + 1; class D items (position 0) take row 0 whatever precedes them:
 //                   min(gap, own position) -- a gap is never larger than the position, and a class D item's is 0
-__device__ __forceinline__ void code_item(uint32_t it, uint32_t prev, const uint32_t *tab /*LDS: the code table*/, uint32_t &e, uint32_t &bits) {
+__device__ __forceinline__ uint32_t item_row(uint32_t it, uint32_t prev) {      // table row of an item: run + 1, or 0 (class D); rows above 16 carry ZRLs
+    const uint32_t pos = it >> 16;
+    return min(pos - (prev >> 16), pos);
+}
+__device__ __forceinline__ void code_item_row(uint32_t it, uint32_t row, const uint32_t *tab /*LDS: the code table*/, uint32_t &e, uint32_t &bits) {
     const int v = (int)(short)(it & 0xFFFFu);
     const int x2 = (v + (v >> 31)) << 1;
     int fb;
     asm("v_ffbh_i32 %0, %1" : "=v"(fb) : "v"(x2));
     const uint32_t al = (uint32_t)x2 << (fb & 31);                            // amplitude bits, left-aligned
-    const uint32_t pos = it >> 16;
-    const uint32_t row = min(pos - (prev >> 16), pos);
     e = tab[kCodeLead + (int)__umul24(row, (uint32_t)kCodeRowStride) + fb];
     bits = (e & 0xFFFF0000u) | (al >> (e & 31u));
+}
+__device__ __forceinline__ void code_item(uint32_t it, uint32_t prev, const uint32_t *tab, uint32_t &e, uint32_t &bits) {
+    code_item_row(it, item_row(it, prev), tab, e, bits);
+}
+
+// z ZRL codes (huffman.c:158-188 codes them as ordinary symbols: 0xF0 is 11111111001, 11 bits) in front of a left-aligned
+// string of <= 27 bits: (bits : 0) >> 11 z under the constant prefix.  z = 3 shifts by 33: the string lands in the low word.
+__device__ __forceinline__ void zrl_prefix(uint32_t bits, uint32_t z /*0..3*/, uint32_t &hi, uint32_t &lo) {
+    static_assert(kZrlBits == 11 && kZrlCode == 0x7F9, "the prefix constants below are three copies of this code");
+    const uint32_t sh = z * 11u;
+    const uint32_t hs = __builtin_amdgcn_alignbit(0u, bits, sh), ls = __builtin_amdgcn_alignbit(bits, 0u, sh);     // (the funnel shifts use sh mod 32)
+    // three copies of the code are 0xFF3FE7FC : 0x80000000; z of them = its top 11 z bits (branch-free: the compiler makes a switch of a constant table)
+    const bool three = z == 3u;
+    const uint32_t chi = 0xFF3FE7FCu & ~(three ? 0u : 0xFFFFFFFFu >> sh);
+    hi = chi | (three ? 0u : hs);
+    lo = three ? (0x80000000u | hs) : ls;
+}
+// sum over the wave of a small per-lane count (0..7): three ballots and scalar population counts instead of a DPP prefix sum
+__device__ __forceinline__ uint32_t wave_sum_3bit(uint32_t v) {
+    return (uint32_t)__popcll(__ballot(v & 1u)) + 2u * (uint32_t)__popcll(__ballot(v & 2u)) + 4u * (uint32_t)__popcll(__ballot(v & 4u));
 }
 
 // OR a left-aligned string (hi:lo, <= 64 bits) into the window at bit `rel`.
@@ -298,7 +321,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     if (bid == 0 && threadIdx.x < kTileGroups) out.tile_ctr_next[threadIdx.x * 32] = 0u;   // all of them: the next launch may form more groups
     const int first = (bid >> sch.grp_shift) * kWavesT + wave;
     const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
-    struct TileGeo { int img, by, tbx0, nblk; bool interior; };
+    struct TileGeo { int img, by, tbx0, nblk, interior; };      // (no padding bytes: a bool at the end made the copy of the struct carry three of them through scratch)
     const auto geo = [&](int tile) {
         TileGeo g;
         g.img = 0;
@@ -706,6 +729,22 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the asm writes are invisible to the compiler's counters
             TSTAMP(8);   // appends
 
+            // The window is written out in the middle of a tile only when the next pass might not fit (very dense tiles).
+            const auto make_room = [&](uint32_t add_bits) {
+                if (__builtin_expect(((cur_bits + add_bits) >> 5) - wbase + 5u > (uint32_t)kWinStr, 0)) {
+                    const uint32_t done = (cur_bits >> 5) - wbase;              // complete words in the window
+                    if (done) {
+                        const uint32_t part = win[kTileRecWords + done];
+                        for (uint32_t j = cl; j < done; j += 64) *str_word(wbase + j) = win[kTileRecWords + j];
+#pragma unroll
+                        for (int i = 0; i < kWinWords / 64; ++i) win[i * 64 + cl] = 0u;
+                        if (cl == 0) win[kTileRecWords] = part;
+                        wbase += done;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // leave no store of a varying count pending
+                    }
+                }
+            };
+
             // ---- 7. Huffman coding of the list (rle.c:83-123, huffman.c:145-188): two items per lane and pass ----
 #pragma unroll 1
             for (uint32_t base = 0; base < nitems; base += (uint32_t)kPassItems) {
@@ -719,32 +758,57 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     if (__builtin_expect(zrl1, 0)) {              // runs >= 16 (rle.c:99-103): ZRL symbols in front
                         const uint32_t z1 = (e1 >> 5) & 3u;
                         l1 += z1 * kZrlBits;
-                        nzrl += (uint32_t)wave_sum_i32((int)z1);
-                        unsigned long long a64 = (unsigned long long)s1 << 32;
-                        for (uint32_t q = 0; q < 3; ++q)
-                            if (q < z1) a64 = (a64 >> kZrlBits) | ((unsigned long long)(kZrlCode << (32u - kZrlBits)) << 32);
-                        h1 = (uint32_t)(a64 >> 32);
-                        lo1 = (uint32_t)a64;
+                        nzrl += wave_sum_3bit(z1);
+                        zrl_prefix(s1, z1, h1, lo1);
                     }
                     const uint32_t incl1 = wave_incl_scan_u32(l1);
                     const uint32_t bits1 = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
                     // (64 items: <= 64 x 60 bits = 120 words -- make room as the long pass does)
-                    if (__builtin_expect(((cur_bits + bits1) >> 5) - wbase + 3u > (uint32_t)kWinStr, 0)) {
-                        const uint32_t done = (cur_bits >> 5) - wbase;
-                        if (done) {
-                            const uint32_t part = win[kTileRecWords + done];
-                            for (uint32_t j = cl; j < done; j += 64) *str_word(wbase + j) = win[kTileRecWords + j];
-#pragma unroll
-                            for (int i = 0; i < kWinWords / 64; ++i) win[i * 64 + cl] = 0u;
-                            if (cl == 0) win[kTileRecWords] = part;
-                            wbase += done;
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        }
-                    }
+                    make_room(bits1);
                     const uint32_t rel1 = (uint32_t)(kTileRecWords * 32) + cur_bits + incl1 - l1 - wbase * 32u;
                     window_or(win, rel1, h1, lo1, zrl1);
                     cur_bits += bits1;
                     break;
+                }
+                if (nitems >= (uint32_t)kQuadMinItems && nitems - base > (uint32_t)kPassItems) {
+                    // A dense list (noise, high qualities: 12 items and more per block) with more than a pass's worth left: FOUR items per
+                    // lane, 256 per pass -- one prefix sum, one window check and one trip round the loop for twice the items: 125
+                    // instructions against 2 x 80.  A pass that holds a ZRL falls through to the two-item pass below; sparse lists, where
+                    // two passes of three hold one, do not try (Q=50: +0.8 % with the attempt, noise -6 %).
+                    const uint4 quad = *reinterpret_cast<const uint4 *>(&stage[base + 4u * cl]);
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_item, (int)quad.w, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+                    // (a run of 16 and more shows in the positions alone -- row = run + 1 -- before any table lookup: a pass that has one
+                    //  costs 14 instructions here; with the test behind the lookups it cost 70, and photo-like tiles have one in two of three)
+                    const uint32_t r0 = item_row(quad.x, p0), r1 = item_row(quad.y, quad.x), r2 = item_row(quad.z, quad.y), r3 = item_row(quad.w, quad.z);
+                    if (__ballot(max(max(r0, r1), max(r2, r3)) > 16u) == 0ull) {
+                        uint32_t e0, e1, e2, e3, s0, s1, s2, s3;
+                        code_item_row(quad.x, r0, s_code, e0, s0);
+                        code_item_row(quad.y, r1, s_code, e1, s1);
+                        code_item_row(quad.z, r2, s_code, e2, s2);
+                        code_item_row(quad.w, r3, s_code, e3, s3);
+                        carry_item = (uint32_t)__builtin_amdgcn_readlane((int)quad.w, 63);
+                        const uint32_t l0 = (e0 >> 8) & 0xFFu, l2 = (e2 >> 8) & 0xFFu;
+                        const uint32_t l01 = l0 + ((e1 >> 8) & 0xFFu), l23 = l2 + ((e3 >> 8) & 0xFFu), lsum = l01 + l23;      // <= 54 + 54 bits
+                        const uint32_t incl_q = wave_incl_scan_u32(lsum);
+                        const uint32_t pass_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl_q, 63);                       // <= 256 x 27 bits = 216 words
+                        make_room(pass_bits);
+                        // the lane's four strings, joined pairwise (<= 54 bits each), then the second pair behind the first: 128 bits, left-aligned
+                        const uint32_t h01 = s0 | __builtin_amdgcn_alignbit(0u, s1, l0), g01 = __builtin_amdgcn_alignbit(s1, 0u, l0);
+                        const uint32_t h23 = s2 | __builtin_amdgcn_alignbit(0u, s3, l2), g23 = __builtin_amdgcn_alignbit(s3, 0u, l2);
+                        const uint32_t a0 = __builtin_amdgcn_alignbit(0u, h23, l01), a1 = __builtin_amdgcn_alignbit(h23, g23, l01), a2 = __builtin_amdgcn_alignbit(g23, 0u, l01);
+                        const bool big = l01 >= 32u;                              // (the funnel shifts use l01 mod 32)
+                        const uint32_t w0 = h01 | (big ? 0u : a0), w1 = g01 | (big ? a0 : a1), w2 = big ? a1 : a2, w3 = big ? a2 : 0u;
+                        const uint32_t rel = (uint32_t)(kTileRecWords * 32) + cur_bits + incl_q - lsum - wbase * 32u;
+                        const uint32_t w = rel >> 5, sh = rel & 31u;
+                        atomicOr(&win[w], __builtin_amdgcn_alignbit(0u, w0, sh));
+                        atomicOr(&win[w + 1], __builtin_amdgcn_alignbit(w0, w1, sh));
+                        atomicOr(&win[w + 2], __builtin_amdgcn_alignbit(w1, w2, sh));
+                        atomicOr(&win[w + 3], __builtin_amdgcn_alignbit(w2, w3, sh));
+                        atomicOr(&win[w + 4], __builtin_amdgcn_alignbit(w3, 0u, sh));     // (zero for all but the pass's longest strings: an OR of 0 is harmless wherever it lands)
+                        cur_bits += pass_bits;
+                        base += (uint32_t)kPassItems;
+                        continue;
+                    }
                 }
                 const uint2 pair = *reinterpret_cast<const uint2 *>(&stage[base + 2u * cl]);
                 const uint32_t ia = pair.x, ib = pair.y;
@@ -760,24 +824,12 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     const uint32_t za = (ea >> 5) & 3u, zb = (eb >> 5) & 3u;
                     la += za * kZrlBits;
                     lb += zb * kZrlBits;
-                    nzrl += (uint32_t)wave_sum_i32((int)(za + zb));
+                    nzrl += wave_sum_3bit(za + zb);
                 }
                 const uint32_t lab = la + lb;
                 const uint32_t incl_b = wave_incl_scan_u32(lab);
                 const uint32_t pass_bits = (uint32_t)__builtin_amdgcn_readlane((int)incl_b, 63);
-                // The window is written out in the middle of a tile only when the next pass might not fit (very dense tiles).
-                if (__builtin_expect(((cur_bits + pass_bits) >> 5) - wbase + 3u > (uint32_t)kWinStr, 0)) {
-                    const uint32_t done = (cur_bits >> 5) - wbase;              // complete words in the window
-                    if (done) {
-                        const uint32_t part = win[kTileRecWords + done];
-                        for (uint32_t j = cl; j < done; j += 64) *str_word(wbase + j) = win[kTileRecWords + j];
-#pragma unroll
-                        for (int i = 0; i < kWinWords / 64; ++i) win[i * 64 + cl] = 0u;
-                        if (cl == 0) win[kTileRecWords] = part;
-                        wbase += done;
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // leave no store of a varying count pending
-                    }
-                }
+                make_room(pass_bits);
                 const uint32_t rel = (uint32_t)(kTileRecWords * 32) + cur_bits + incl_b - lab - wbase * 32u;
                 if (__builtin_expect(!any_zrl, 1)) {
                     // join the lane's two strings: (bits_a : bits_b >> len_a), <= 54 bits
@@ -786,17 +838,10 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     window_or(win, rel, hi, lo, true);
                 } else {
                     // symbol by symbol, each with its ZRLs in front (huffman.c:158-188 codes them as ordinary symbols)
-                    const auto with_zrl = [&](uint32_t bits, uint32_t z, uint32_t &hi, uint32_t &lo) {
-                        unsigned long long a64 = (unsigned long long)bits << 32;
-                        for (uint32_t q = 0; q < 3; ++q)
-                            if (q < z) a64 = (a64 >> kZrlBits) | ((unsigned long long)(kZrlCode << (32u - kZrlBits)) << 32);
-                        hi = (uint32_t)(a64 >> 32);
-                        lo = (uint32_t)a64;
-                    };
                     uint32_t hi, lo;
-                    with_zrl(sa, (ea >> 5) & 3u, hi, lo);
+                    zrl_prefix(sa, (ea >> 5) & 3u, hi, lo);
                     window_or(win, rel, hi, lo, true);
-                    with_zrl(sb, (eb >> 5) & 3u, hi, lo);
+                    zrl_prefix(sb, (eb >> 5) & 3u, hi, lo);
                     window_or(win, rel + la, hi, lo, true);
                 }
                 cur_bits += pass_bits;

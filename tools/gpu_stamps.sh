@@ -4,6 +4,6 @@ set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/stamps
 for v in stamps "$@"; do
-JPEGAMD_LIB=$PWD/build_variants/lib_$v.so timeout -k 10 200 python tools/stamp_profile_tile.py > gpurun_out/stamps/$v.txt 2>&1 || { tail -20 gpurun_out/stamps/$v.txt; exit 1; }
+JPEGAMD_LIB=$PWD/build_variants/lib_$v.so timeout -k 10 200 python tools/stamp_profile_tile.py $STAMP_ARGS > gpurun_out/stamps/$v.txt 2>&1 || { tail -20 gpurun_out/stamps/$v.txt; exit 1; }
 echo "== $v"; tail -16 gpurun_out/stamps/$v.txt
 done

@@ -16,14 +16,16 @@ import jpegamd
 
 w = h = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-bmp = jpegamd.synth_bmp(w, h, seed, 0, 0)
+quality = int(sys.argv[3]) if len(sys.argv) > 3 else 0                 # 0: the default (50)
+kind = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+bmp = jpegamd.synth_bmp(w, h, seed, kind, 0)
 img, off = jpegamd.parse_bmp(bmp)
 px = torch.frombuffer(bytearray(bmp[off:off + img.row_stride * h]), dtype=torch.uint8).cuda()
 enc = jpegamd.Encoder(w, h)
 cap = 4096 + w * h
 out = torch.empty(cap, dtype=torch.uint8, device="cuda")
 size = torch.zeros(1, dtype=torch.int64, device="cuda")
-d = jpegamd.Encoder.image(px.data_ptr(), w, h, img.row_stride, True)
+d = jpegamd.Encoder.image(px.data_ptr(), w, h, img.row_stride, True, jpegamd.ORDER_BGR, quality)
 for _ in range(3):
     enc.encode_async(d, out.data_ptr(), cap, size.data_ptr(), True, 0)
     enc.finish()
