@@ -71,7 +71,7 @@ static int segs_for(int w, int h, int *bw, int *bh, int *spr, int seg_tiles = kS
     return blocks_h * per_row;
 }
 
-extern "C" const char *jpegamd_version(void) { return "jpegamd 0.2 (gfx950)"; }
+extern "C" const char *jpegamd_version(void) { return "jpegamd 0.3 (gfx950)"; }
 
 extern "C" int32_t jpegamd_segment_meta_words(void) { return kSegMetaWords; }
 
