@@ -14,11 +14,12 @@ Workloads (`--workload`, default `auto`):
              default run and reported as roofline.one_image_per_launch.
              This is what `auto` selects at EVERY N: the driver derives the scaling efficiency from the per-N values, so
              the per-rank work has to be the same at N = 1 and N = 8 (weak scaling).
-  batch4096  BASELINE.json configs[3]: independent 4096x4096 images, 8 per rank per step (N = 8: the batch of 64),
-             distinct seeds (tests/golden/batch4096.json holds the compiled reference's answers for all 64), by default one
-             launch per step; every finished bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
+  batch4096  BASELINE.json configs[3]: the batch of 64 independent 4096x4096 images, 64 / N per rank per step (N = 8: 8 each,
+             one launch; N = 1: all 64, two launches of 32 = JPEGAMD_MAX_BATCH, as much work per launch as eight 8192^2),
+             distinct seeds (tests/golden/batch4096.json holds the compiled reference's answers for all 64); every finished
+             bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
 Reference quantisation table (Q=50) unless --quality says otherwise; pixel rows resident in HBM; output = complete
-JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_encode -> k_segment_merge -> k_finalize) over the
+JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_encode -> k_stitch) over the
 step's images, on one HIP stream by default (`--streams`: k_tile_encode is a persistent kernel that fills the GPU; launches on
 several streams queue behind each other's workgroups and were measured slower); every step is a complete encode.  With N > 1 every rank
 encodes its own images (weak scaling, no data-path collective inside the encode) and the finished bitstreams are
@@ -27,15 +28,15 @@ collected at rank 0 with one asynchronous RCCL gather per `--gather-every` image
 
 Extra objects on the JSON line:
   "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes of ONE launch (BMP rows read + JFIF
-                  bytes written, per image x images_per_launch) / SUM of the three kernels' durations / 8 TB/s.  Durations are
+                  bytes written, per image x images_per_launch) / SUM of the two kernels' durations / 8 TB/s.  Durations are
                   HIP-event timed inside this run through the C-ABI's event ring -- every kernel launched with its own begin / end
                   events on the stream it runs on (a kernel's own duration, as a kernel trace shows it) -- in SEPARATE single-stream
                   passes behind the timed region, whose own launches carry no events: once right behind the region (`sustained`) and
                   once 250 ms later (the headline figures; the state a kernel trace of `bench.py --streams 1` sees).
                   `dominant_frac` is the same bytes over k_tile_encode alone, `hbm_read_frac` the read bytes alone over the sum,
                   `per_image_us` the sum divided by images_per_launch, `one_image_per_launch` the literal configs[2] launch shape.
-  "configs3"      N > 1 (or --force-gather): a short leg of BASELINE configs[3] behind the main one -- 8 independent 4096^2 images
-                  per rank and step in one launch, every bitstream gathered at rank 0.
+  "configs3"      N > 1 (or --force-gather): a short leg of BASELINE configs[3] behind the main one -- 64 / N independent 4096^2 images
+                  per rank and step (launches of up to 32), every bitstream gathered at rank 0.
   "cpu_baseline"  the compiled reference natural_c (oracle/_ref), single thread, on a bounded sample: with its own
                   flags (no -O) and with -O2; rank 0, N == 1 only.
 """
@@ -56,7 +57,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 ROTATE = int(os.environ.get("JPEGAMD_BENCH_ROTATE", "3"))   # image8192: rotating inputs per rank (1 = experiment: the input stays in the 256 MB Infinity Cache)
-BATCH_PER_RANK = 8             # batch4096: images per rank per step
+BATCH_TOTAL = 64               # batch4096: BASELINE configs[3]'s batch, split over the ranks
 
 
 def parse_args():
@@ -72,8 +73,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-image-pass", action="store_true",
                     help="skip the one-image-per-launch comparison pass (kernel traces of the batched default: every launch then codes the same number of images)")
-    ap.add_argument("--images-per-launch", type=int, default=0, choices=[0, 1, 2, 4, 8],
-                    help="images coded by ONE launch of each kernel (jpegamd_encode_batch_async); 0 = 8 (image8192 then codes 8 images per step)")
+    ap.add_argument("--images-per-launch", type=int, default=0, choices=[0, 1, 2, 4, 8, 16, 32],
+                    help="images coded by ONE launch of each kernel (jpegamd_encode_batch_async); 0 = 8 for image8192 (8 images per step), "
+                         "min(32, images per rank) for batch4096")
     ap.add_argument("--roofline-idle-ms", type=float, default=250.0, help="idle time in front of the second single-stream roofline pass")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (one encoder context each) the launches alternate over.  One by default: k_tile_encode is a "
@@ -221,8 +223,8 @@ def main():
             nrot = ROTATE if B == 1 else max(ROTATE, 2 * B)          # a launch reads B distinct pictures, two launches never the same ones
             seeds = [1000 + rank * nrot + i for i in range(nrot)]
         else:
-            w, h, ips = args.width or 4096, args.height or 4096, BATCH_PER_RANK
-            seeds = [2000 + rank * BATCH_PER_RANK + i for i in range(BATCH_PER_RANK)]
+            w, h, ips = args.width or 4096, args.height or 4096, max(B, BATCH_TOTAL // world)
+            seeds = [2000 + (rank * ips + i) % BATCH_TOTAL for i in range(ips)]
         inputs, stride, first_bmp = make_inputs(args, rank, torch, jpegamd, w, h, seeds)
         nimg = len(inputs)
         nstreams = max(1, args.streams)
@@ -402,7 +404,7 @@ def main():
 
         if primary:
             h_tr, h_en, h_pk, _ = single_stream_pass(B)
-            sustained = {"transform_us": round(h_tr / 1e3, 2), "merge_us": round(h_en / 1e3, 2), "finalize_us": round(h_pk / 1e3, 2),
+            sustained = {"transform_us": round(h_tr / 1e3, 2), "stitch_us": round(h_pk / 1e3, 2),
                          "sum_kernels_us": round((h_tr + h_en + h_pk) / 1e3, 2), "measured": f"single-stream pass of {P - SKIP} launches right behind the timed region"}
             time.sleep(args.roofline_idle_ms / 1e3)
         ns_tr, ns_en, ns_pk, ns_tot = single_stream_pass(B)
@@ -459,7 +461,7 @@ def main():
                 for r in range(world):
                     for k in range(used):
                         n = last - (used - 1) + k
-                        ent = gold.get(f"{w}x{h}_seed{2000 + r * BATCH_PER_RANK + n % nimg}_kind0_q50")
+                        ent = gold.get(f"{w}x{h}_seed{2000 + (r * ips + n % nimg) % BATCH_TOTAL}_kind0_q50")
                         if ent and hashlib.sha256(per_rank[r][k]).hexdigest() != ent["sha256"]:
                             parity, parity_ok = f"MISMATCH vs natural_c golden (rank {r}, image {n})", False
 
@@ -483,12 +485,12 @@ def main():
                 traffic = None
         one = None
         if single_ns:
-            one = {"transform_us": round(single_ns[0] / 1e3, 2), "merge_us": round(single_ns[1] / 1e3, 2), "finalize_us": round(single_ns[2] / 1e3, 2),
+            one = {"transform_us": round(single_ns[0] / 1e3, 2), "stitch_us": round(single_ns[2] / 1e3, 2),
                    "sum_kernels_us": round(sum(single_ns[:3]) / 1e3, 2), "achieved": round(algo_bytes / sum(single_ns[:3]), 1),
                    "frac": round(algo_bytes / sum(single_ns[:3]) / HBM_PEAK_GBS, 4),
                    "measured": f"single-stream pass of {P - SKIP} single-image launches (the literal BASELINE configs[2] launch shape) behind the batched one"}
         if workload == "batch4096":
-            what = " (BASELINE configs[3]: batch of 64 at 8 ranks)"
+            what = f" (BASELINE configs[3]: the batch of 64, {ips} per rank)"
         elif B == 1:
             what = " (BASELINE configs[2])"
         else:
@@ -515,14 +517,14 @@ def main():
                        "streams_per_rank": nstreams,
                        "parallelism": f"dp{world} (independent images per rank"
                                       + (", async RCCL gather of bitstreams to rank 0)" if dist is not None else ")")},
-            "roofline": {"bound": "hbm", "kernel": "k_tile_encode + k_segment_merge + k_finalize (sum of durations, SURVEY.md 8d)",
+            "roofline": {"bound": "hbm", "kernel": "k_tile_encode + k_stitch (sum of durations, SURVEY.md 8d)",
                          "achieved": round(launch_bytes / ns_sum, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(launch_bytes / ns_sum / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes": launch_bytes, "images_per_launch": B,
                          "hbm_read_frac": round(read_bytes * B / ns_sum / HBM_PEAK_GBS, 4),
                          "dominant_kernel": "k_tile_encode", "dominant_frac": round(launch_bytes / ns_tr / HBM_PEAK_GBS, 4),
                          "per_image_us": round(ns_sum / B / 1e3, 2),
-                         "kernel_us": round(ns_tr / 1e3, 2), "merge_us": round(ns_en / 1e3, 2), "finalize_us": round(ns_pk / 1e3, 2),
+                         "kernel_us": round(ns_tr / 1e3, 2), "stitch_us": round(ns_pk / 1e3, 2),
                          "sum_kernels_us": round(ns_sum / 1e3, 2), "first_to_last_event_us": round(ns_tot / 1e3, 2),
                          "throughput_frac": round(algo_bytes * ips / (elapsed / K * 1e9) / HBM_PEAK_GBS, 4),
                          "measured": roof_note,
@@ -539,11 +541,13 @@ def main():
         return line, parity_ok, first_bmp
 
     workload = args.workload if args.workload != "auto" else "image8192"
-    line, parity_ok, first_bmp = measure(workload, args.steps, args.warmup, args.images_per_launch or 8, True)
+    world_ = int(os.environ.get("WORLD_SIZE", "1"))
+    ipl = args.images_per_launch or (8 if workload == "image8192" else min(32, max(1, BATCH_TOTAL // world_)))
+    line, parity_ok, first_bmp = measure(workload, args.steps, args.warmup, ipl, True)
     # N > 1: BASELINE configs[3] (the batch of 64 4096^2 images at 8 ranks) as a short second leg, so that a multi-GPU run of the
     # default command reports the gathered-batch configuration as well
     if dist is not None and workload == "image8192" and args.configs3_steps > 0 and not (args.width or args.height):
-        c3, c3_ok, _ = measure("batch4096", args.configs3_steps, 5, 8, False)
+        c3, c3_ok, _ = measure("batch4096", args.configs3_steps, 5, min(32, max(1, BATCH_TOTAL // world_)), False)
         parity_ok = parity_ok and c3_ok
         if rank == 0:
             line["configs3"] = {k: c3[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "jfif_bytes", "parity")}

@@ -126,7 +126,7 @@ int32_t jpegamd_encode_async(JpegAmdEncoder *enc, const JpegAmdImage *img, void 
  * segments of one image (e.g. jpegamd_encoder_create(W, count * H) for count W x H images -- max_height may go up to
  * JPEGAMD_MAX_BATCH x 65535 for that purpose); JPEGAMD_ERR_TOO_LARGE otherwise.
  * jpegamd_encoder_finish then reports the LAST image's size and the batch's summed counters. */
-#define JPEGAMD_MAX_BATCH 8
+#define JPEGAMD_MAX_BATCH 32
 int32_t jpegamd_encode_batch_async(JpegAmdEncoder *enc, const JpegAmdImage *imgs, int32_t count, void *const *outs_dev,
                                    uint64_t out_capacity, uint64_t *const *out_sizes_dev, int32_t with_container,
                                    void *stream);

@@ -1,6 +1,7 @@
 // jpegamd_api.cpp -- C-ABI host layer over the HIP kernels (include/jpeg_compression.h).
 //
-// Level 1 (jpegamd_*): device-resident, stream-ordered encode: k_tile_encode -> k_segment_merge -> k_finalize.
+// Level 1 (jpegamd_*): device-resident, stream-ordered encode: k_tile_encode -> k_stitch (whole images); the block-row shards of
+//          one image over several GPUs keep k_segment_merge / k_finalize around the exchange.
 // Level 2 (JpegCompression_Init / convertToJpeg): the reference's accelerator boundary
 //          (dsp_port/jpeg_compression/src/jpeg_compression.c:6-33,35-216).
 // There is no CPU fallback: without a HIP device every compute entry fails.
@@ -42,6 +43,9 @@ struct JpegAmdEncoder {
     MfmaTables *tables_host = nullptr;          // this context's own staging copy (contexts may be driven from different threads)
     uint32_t *tile_head = nullptr, *tile_over = nullptr, *tile_ctr = nullptr, *code_tab = nullptr;
     int ctr_set = 0;                    // which half of tile_ctr the next k_tile_encode launch uses
+    unsigned long long *desc = nullptr; // k_stitch's hand-off granules: three arrays of max_wgs (bits, tail, 0xFF bytes)
+    int max_wgs = 0;
+    uint32_t epoch = 0;                 // 1 .. 16383: tag of the last k_stitch launch's granules
     int poison_tile = -1;               // jpegamd_debug_poison_tile_record: the next encode overwrites this tile's record word 0 ...
     uint32_t poison_value = 0;          // ... with this value, between k_tile_encode and k_segment_merge
     unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
@@ -51,7 +55,7 @@ struct JpegAmdEncoder {
     int prefix_w = -1, prefix_h = -1, prefix_q = -1;
     // profiling: a ring of event quadruples so callers can time many async encodes and read
     // the per-kernel durations after ONE synchronisation
-    struct EventSet { hipEvent_t ev[6]; };     // begin / end of k_tile_encode, k_segment_merge, k_finalize (the kernels' own timestamps)
+    struct EventSet { hipEvent_t ev[6]; bool merged; };   // begin / end of k_tile_encode, [k_segment_merge,] k_stitch or k_finalize (the kernels' own timestamps)
     std::vector<EventSet> ring;
     uint64_t calls = 0;          // encodes enqueued since profiling was (re)enabled
     int last_slot = -1;
@@ -71,7 +75,7 @@ static int segs_for(int w, int h, int *bw, int *bh, int *spr, int seg_tiles = kS
     return blocks_h * per_row;
 }
 
-extern "C" const char *jpegamd_version(void) { return "jpegamd 0.3 (gfx950)"; }
+extern "C" const char *jpegamd_version(void) { return "jpegamd 0.4 (gfx950)"; }
 
 extern "C" int32_t jpegamd_segment_meta_words(void) { return kSegMetaWords; }
 
@@ -179,6 +183,9 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY_CREATE(hipMalloc((void **)&e->code_tab, kCodeWords * sizeof(uint32_t)));
     HIP_TRY_CREATE(hipMalloc((void **)&e->tile_ctr, 2 * 64 * 128));      // two sets of ticket-group cache lines, used alternately
     HIP_TRY_CREATE(hipMemset(e->tile_ctr, 0, 2 * 64 * 128));
+    e->max_wgs = e->max_segs + 2;                                          // (a picture never has more workgroups than segments)
+    HIP_TRY_CREATE(hipMalloc((void **)&e->desc, 3 * (size_t)e->max_wgs * sizeof(unsigned long long)));
+    HIP_TRY_CREATE(hipMemset(e->desc, 0, 3 * (size_t)e->max_wgs * sizeof(unsigned long long)));
     if (std::getenv("JPEGAMD_STAMPS")) {
         const size_t n = (size_t)(e->max_segs > 4096 ? e->max_segs : 4096) * 16 * sizeof(unsigned long long);
         HIP_TRY_CREATE(hipMalloc((void **)&e->stamps_dev, n));
@@ -201,7 +208,7 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     if (e->pending) hipStreamSynchronize(e->last_stream);
     hipFree(e->seg.words); hipFree(e->seg.bits); hipFree(e->seg.syms); hipFree(e->seg.exact); hipFree(e->seg.edge); hipFree(e->seg.ffin); hipFree(e->seg.grp_bits); hipFree(e->seg.grp_ff);
     hipFree(e->huff); hipFree(e->prefix); hipFree(e->stats_dev); hipFree(e->tables_dev);
-    hipFree(e->tile_head); hipFree(e->tile_over); hipFree(e->code_tab); hipFree(e->tile_ctr); hipFree(e->stamps_dev);
+    hipFree(e->tile_head); hipFree(e->tile_over); hipFree(e->code_tab); hipFree(e->tile_ctr); hipFree(e->desc); hipFree(e->stamps_dev);
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     delete e->tables_host;
     delete e;
@@ -214,7 +221,7 @@ extern "C" int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *e, int32_t slot
     for (auto &set : e->ring) for (auto &ev : set.ev) if (ev) hipEventDestroy(ev);
     e->ring.clear();
     e->ring.resize((size_t)slots);
-    for (auto &set : e->ring) for (auto &ev : set.ev) HIP_TRY(hipEventCreate(&ev));
+    for (auto &set : e->ring) { set.merged = false; for (auto &ev : set.ev) HIP_TRY(hipEventCreate(&ev)); }
     e->calls = 0;
     e->last_slot = -1;
     return JPEGAMD_OK;
@@ -225,7 +232,8 @@ static int32_t read_slot(JpegAmdEncoder *e, int slot, JpegAmdStats *stats) {
     hipEvent_t *ev = e->ring[(size_t)slot].ev;
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); stats->ns_transform = (uint64_t)((double)ms * 1e6);
-    HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ns_entropy = (uint64_t)((double)ms * 1e6);
+    stats->ns_entropy = 0;                                     // (whole images: there is no separate merge kernel)
+    if (e->ring[(size_t)slot].merged) { HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); stats->ns_entropy = (uint64_t)((double)ms * 1e6); }
     HIP_TRY(hipEventElapsedTime(&ms, ev[4], ev[5])); stats->ns_pack = (uint64_t)((double)ms * 1e6);
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[5])); stats->ns_total = (uint64_t)((double)ms * 1e6);     // first begin .. last end: includes the launch gaps
     return JPEGAMD_OK;
@@ -293,9 +301,9 @@ static int32_t describe(const JpegAmdEncoder *e, const JpegAmdImage *img, ImageD
     return JPEGAMD_OK;
 }
 
-// k_tile_encode, then k_segment_merge.
-static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
-                                        void *stream, hipEvent_t *ev = nullptr /*4: begin/end of the two kernels*/) {
+// k_tile_encode (+ the fault injection of the tests).
+static int launch_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
+                            void *stream, hipEvent_t *ev = nullptr /*2: begin/end*/) {
     TransformOutM to;
     std::memset(&to, 0, sizeof(to));
     to.tables = e->tables_dev; to.stamps = e->stamps_dev;
@@ -313,6 +321,13 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
             return (int)hipErrorUnknown;
         e->poison_tile = -1;
     }
+    return 0;
+}
+
+// k_tile_encode, then k_segment_merge (block-row shards, stage taps).
+static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, bool taps, int8_t *ty, int16_t *tzz, uint64_t *tmask,
+                                        void *stream, hipEvent_t *ev = nullptr /*4: begin/end of the two kernels*/) {
+    if (int err = launch_transform(e, im, taps, ty, tzz, tmask, stream, ev)) return err;
     MergeArgs ea;
     std::memset(&ea, 0, sizeof(ea));
     ea.tile_head = e->tile_head; ea.tile_over = e->tile_over;
@@ -326,19 +341,30 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     return launch_segment_merge(ea, stream, ev ? (void *const *)(ev + 2) : nullptr);
 }
 
-static int run_finalize_batch(JpegAmdEncoder *e, const ImageDesc &im, void *const *outs_dev, uint64_t out_capacity,
-                              uint64_t *const *out_sizes_dev, int32_t with_container, hipStream_t stream, hipEvent_t *ev = nullptr) {
-    FinalizeArgs fa;
-    std::memset(&fa, 0, sizeof(fa));
-    fa.seg = e->seg;
-    fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
-    fa.batch = im.batch;
-    fa.use_groups = (im.num_segs % kSegGroup == 0) ? 1 : 0;      // every image then starts on a group boundary
-    for (int i = 0; i < im.batch; ++i) { fa.out[i] = (uint8_t *)outs_dev[i]; fa.out_size[i] = out_sizes_dev[i]; }
-    fa.out_capacity = out_capacity; fa.stats = e->stats_dev;
-    fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
-    fa.write_eoi = with_container ? 1 : 0;
-    return launch_finalize(fa, stream, (void *const *)ev);
+// k_stitch over the tiles k_tile_encode left: whole images, one or a batch.
+static int run_stitch(JpegAmdEncoder *e, const ImageDesc &im, void *const *outs_dev, uint64_t out_capacity,
+                      uint64_t *const *out_sizes_dev, int32_t with_container, hipStream_t stream, hipEvent_t *ev = nullptr) {
+    StitchArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.tile_head = e->tile_head; sa.tile_over = e->tile_over; sa.huff = e->huff;
+    sa.num_segs = im.num_segs; sa.segs_per_row = im.segs_per_row; sa.tiles_per_row = im.tiles_per_row;
+    sa.seg_tiles = im.seg_tiles; sa.tiles_per_image = im.num_tiles;
+    sa.batch = im.batch; sa.wgs_per_image = stitch_workgroups(im.num_segs);
+    if ((int64_t)sa.batch * sa.wgs_per_image > e->max_wgs) return (int)hipErrorInvalidValue;
+    // a fresh epoch per launch: granules of older launches never match (no zeroing between launches); the arrays are cleared
+    // when the 14-bit tag wraps
+    if (e->epoch >= 16383u) {
+        if (hipMemsetAsync(e->desc, 0, 3 * (size_t)e->max_wgs * sizeof(unsigned long long), stream) != hipSuccess) return (int)hipErrorUnknown;
+        e->epoch = 0;
+    }
+    sa.epoch = ++e->epoch;
+    sa.desc_bits = e->desc; sa.desc_tail = e->desc + e->max_wgs; sa.desc_ff = e->desc + 2 * (size_t)e->max_wgs;
+    sa.seg_syms = e->seg.syms; sa.seg_exact = e->seg.exact;
+    for (int i = 0; i < im.batch; ++i) { sa.out[i] = (uint8_t *)outs_dev[i]; sa.out_size[i] = out_sizes_dev[i]; }
+    sa.out_capacity = out_capacity; sa.stats = e->stats_dev; sa.status = &e->stats_dev->status;
+    sa.prefix = e->prefix; sa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
+    sa.write_eoi = with_container ? 1 : 0;
+    return launch_stitch(sa, stream, (void *const *)ev);
 }
 
 static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, uint64_t out_capacity, uint64_t *out_size_dev,
@@ -466,9 +492,10 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         ev = e->ring[(size_t)e->last_slot].ev;
         ++e->calls;
     }
-    if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
-    if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream, ev ? ev + 4 : nullptr,
-                     im.num_segs % kSegGroup == 0)) return JPEGAMD_ERR_HIP;
+    if (launch_transform(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+    void *const outs[1] = {out_dev};
+    uint64_t *const sizes[1] = {out_size_dev};
+    if (run_stitch(e, im, outs, out_capacity, sizes, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
     e->last_stream = stream;
     e->pending = true;
@@ -516,8 +543,8 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
         ev = e->ring[(size_t)e->last_slot].ev;
         ++e->calls;
     }
-    if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
-    if (run_finalize_batch(e, im, outs_dev, out_capacity, out_sizes_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    if (launch_transform(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+    if (run_stitch(e, im, outs_dev, out_capacity, out_sizes_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
     e->last_segs = count * im.num_segs;
     e->last_stream = stream;
     e->pending = true;
@@ -549,6 +576,7 @@ extern "C" int32_t jpegamd_encoder_finish(JpegAmdEncoder *e, JpegAmdStats *stats
             if (rc) return rc;
         }
     }
+    if (e->mirror.status & 4u) return JPEGAMD_ERR_HIP;              // a look-back of k_stitch gave up waiting (never seen; the spins are bounded so that it cannot hang)
     if (e->mirror.status & 2u) return JPEGAMD_ERR_RLE_CAPACITY;     // a tile record outside its reservation (corrupt scratch)
     return (e->mirror.status & 1u) ? JPEGAMD_ERR_HUFF_CAPACITY : JPEGAMD_OK;
 }

@@ -95,7 +95,7 @@ struct ScanStats {                   // device-side per-call record
     uint32_t pad;
 };
 
-constexpr int kMaxBatch = 8;            // images of one geometry coded by ONE launch of each kernel (jpegamd_encode_batch_async)
+constexpr int kMaxBatch = 32;           // images of one geometry coded by ONE launch of each kernel (jpegamd_encode_batch_async)
 
 struct ImageDesc {
     const uint8_t *pixels;              // image 0 (== batch_pixels[0])
@@ -174,6 +174,33 @@ struct FinalizeArgs {
 };
 int launch_finalize(const FinalizeArgs &a, void *stream, void *const *ev = nullptr);
 int finalize_chunks(int num_segs);
+
+// k_stitch (jpegamd_stitch.hip): whole images -- the tiles' strings -> the finished entropy-coded segment in ONE pass (what
+// k_segment_merge + k_finalize do in two for the block-row shards of one image over several GPUs).
+// Hand-off granules between workgroups: bits 63..50 the launch epoch, 49..48 the status (1 = this workgroup's own value,
+// 2 = inclusive of every workgroup in front of it in the picture), 47..0 the value.  The arrays are zeroed when the context
+// is created and whenever the 14-bit epoch wraps; a granule of an older launch never matches the epoch.
+struct StitchArgs {
+    const uint32_t *tile_head, *tile_over;
+    const uint32_t *huff;           // [272] (len << 16) | code: AC by run/size symbol, then 16 DC sizes
+    int32_t num_segs, segs_per_row, tiles_per_row;     // per image
+    int32_t seg_tiles;              // tiles per segment: kSegTiles or kSegTilesBatch
+    int32_t tiles_per_image;
+    int32_t batch, wgs_per_image;   // grid = batch * wgs_per_image
+    uint32_t epoch;                 // 1 .. 16383
+    unsigned long long *desc_bits, *desc_tail, *desc_ff;   // [batch * wgs_per_image] granules
+    uint32_t *seg_syms, *seg_exact; // [batch * num_segs] per-segment counters (summed on request)
+    uint8_t *out[kMaxBatch];
+    uint64_t out_capacity;          // of every output
+    uint64_t *out_size[kMaxBatch];  // device
+    ScanStats *stats;               // device
+    uint32_t *status;               // &stats->status: bit 0 output capacity, bit 1 corrupt tile record, bit 2 a look-back gave up
+    const uint8_t *prefix;
+    int32_t prefix_len;
+    int32_t write_eoi;
+};
+int launch_stitch(const StitchArgs &a, void *stream, void *const *ev = nullptr);
+int stitch_workgroups(int num_segs);
 
 // Segment exchange for one image sharded over GPUs by block rows (jpegamd_finalize.hip): dense copy of the used words of
 // segments [s0, s1) + kSegMetaWords words of metadata per segment, and back.

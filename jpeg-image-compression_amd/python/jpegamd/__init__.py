@@ -118,7 +118,7 @@ def quant_table(quality: int = 50):
     return table
 
 
-MAX_BATCH = 8                                                # JPEGAMD_MAX_BATCH
+MAX_BATCH = 32                                               # JPEGAMD_MAX_BATCH
 SEG_META_WORDS = int(lib.jpegamd_segment_meta_words())      # metadata words per segment in the sharded-image exchange
 
 

@@ -258,9 +258,11 @@ def test_batched_launch_at_full_size_against_reference_hashes(jpegamd, dev):
     run(enc, 8192, 8192, list(range(1000, 1008)), 10, large, px)
     run(enc, 8192, 8192, list(range(1000, 1008)), 90, large, px)
     del px
-    enc = jpegamd.Encoder(4096, 8 * 4096)
-    px = pixels(4096, 4096, range(2000, 2008), batch)
+    # configs[3]'s images: eight per launch, and JPEGAMD_MAX_BATCH (32) per launch -- as much work as a launch of eight 8192^2
+    enc = jpegamd.Encoder(4096, 32 * 4096)
+    px = pixels(4096, 4096, range(2000, 2032), batch)
     run(enc, 4096, 4096, list(range(2000, 2008)), 50, batch, px)
+    run(enc, 4096, 4096, list(range(2000, 2032)), 50, batch, px)
 
 
 def test_row_stride_of_16_mib_and_more(jpegamd, oracle, dev):
@@ -320,8 +322,9 @@ def test_reference_sample_images(jpegamd, dev):
 
 @pytest.mark.gpu
 def test_profiling_ring_reports_the_kernels_own_durations(jpegamd, dev):
-    """jpegamd_encoder_set_profiling: every kernel carries its own begin / end events, so the three durations are positive,
-    their sum is below the first-begin-to-last-end span (launch gaps), and a 4x larger image takes longer."""
+    """jpegamd_encoder_set_profiling: every kernel carries its own begin / end events, so the durations are positive, their sum is
+    below the first-begin-to-last-end span (launch gaps), and a 4x larger image takes longer.  Whole images run two kernels
+    (k_tile_encode, k_stitch): the merge figure of the block-row path stays 0."""
     res = {}
     for (w, h) in ((1024, 1024), (2048, 2048)):
         enc = jpegamd.Encoder(w, h)
@@ -337,7 +340,7 @@ def test_profiling_ring_reports_the_kernels_own_durations(jpegamd, dev):
         enc.finish()
         prof = [enc.profile(s) for s in range(2, 8)]
         for p in prof:
-            assert p.ns_transform > 0 and p.ns_entropy > 0 and p.ns_pack > 0
+            assert p.ns_transform > 0 and p.ns_entropy == 0 and p.ns_pack > 0
             assert p.ns_transform + p.ns_entropy + p.ns_pack <= p.ns_total
             assert p.ns_total < 5_000_000
         res[w] = sum(p.ns_transform for p in prof) / len(prof)
@@ -548,7 +551,6 @@ def test_one_image_sharded_by_block_rows(jpegamd, oracle, dev):
         assert got == oracle.encode_bmp(bmp), (w, h, kind, ranks)
 
 
-@pytest.mark.gpu
 def _segment_meta(bits: np.ndarray, word_off: int):
     """Metadata of one unstuffed segment string as k_segment_merge leaves it (jpegamd_export_segments' 12 words): bit count, word
     offset, (first 8 bits << 8) | last 7 bits, and for each byte phase p the 0xFF bytes lying WHOLLY inside the string when its

@@ -280,7 +280,7 @@ def test_compute_fails_loudly_without_device(jpegamd, tmp_path):
     img = jpegamd.Image(0, 8, 8, 24, 1, jpegamd.ORDER_BGR, 0)
     one = (C.c_void_p * 1)(None)
     assert jpegamd.lib.jpegamd_encode_batch_async(None, C.byref(img), 1, one, 1024, one, 1, None) == -1     # JPEGAMD_ERR_ARG
-    assert jpegamd.MAX_BATCH == 8
+    assert jpegamd.MAX_BATCH == 32
 
 
 def test_cli_argv_contract(tmp_path):

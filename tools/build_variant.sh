@@ -15,6 +15,6 @@ for f in $PKG/csrc/*.hip; do
   pids="$pids $!"
 done
 for p in $pids; do wait $p || { echo "build_variant $NAME: compile failed"; exit 1; }; done
-others=$(ls $PKG/csrc/*.o $PKG/host/*.o | grep -v -E "csrc/jpegamd_(entropy|finalize|tile_pipeline)\.o")
+others=$(ls $PKG/csrc/*.o $PKG/host/*.o | grep -v -E "csrc/jpegamd_(entropy|finalize|stitch|tile_pipeline)\.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build_variants/lib_$NAME.so $OBJ/*.o $others
 echo built build_variants/lib_$NAME.so
