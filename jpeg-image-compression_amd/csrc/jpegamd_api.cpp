@@ -43,7 +43,7 @@ struct JpegAmdEncoder {
     MfmaTables *tables_host = nullptr;          // this context's own staging copy (contexts may be driven from different threads)
     uint32_t *tile_head = nullptr, *tile_over = nullptr, *tile_ctr = nullptr, *code_tab = nullptr;
     int ctr_set = 0;                    // which half of tile_ctr the next k_tile_encode launch uses
-    unsigned long long *desc = nullptr; // k_stitch's hand-off granules: three arrays of max_wgs (bits, tail, 0xFF bytes)
+    uint32_t *desc = nullptr;           // k_stitch's hand-off granules: max_wgs x 16 bytes, then max_wgs x 8 counts in full
     int max_wgs = 0;
     uint32_t epoch = 0;                 // 1 .. 16383: tag of the last k_stitch launch's granules
     int poison_tile = -1;               // jpegamd_debug_poison_tile_record: the next encode overwrites this tile's record word 0 ...
@@ -184,8 +184,8 @@ extern "C" int32_t jpegamd_encoder_create(JpegAmdEncoder **out, int32_t max_widt
     HIP_TRY_CREATE(hipMalloc((void **)&e->tile_ctr, 2 * 64 * 128));      // two sets of ticket-group cache lines, used alternately
     HIP_TRY_CREATE(hipMemset(e->tile_ctr, 0, 2 * 64 * 128));
     e->max_wgs = e->max_segs + 2;                                          // (a picture never has more workgroups than segments)
-    HIP_TRY_CREATE(hipMalloc((void **)&e->desc, 3 * (size_t)e->max_wgs * sizeof(unsigned long long)));
-    HIP_TRY_CREATE(hipMemset(e->desc, 0, 3 * (size_t)e->max_wgs * sizeof(unsigned long long)));
+    HIP_TRY_CREATE(hipMalloc((void **)&e->desc, 12 * (size_t)e->max_wgs * sizeof(uint32_t)));
+    HIP_TRY_CREATE(hipMemset(e->desc, 0, 12 * (size_t)e->max_wgs * sizeof(uint32_t)));
     if (std::getenv("JPEGAMD_STAMPS")) {
         const size_t n = (size_t)(e->max_segs > 4096 ? e->max_segs : 4096) * 16 * sizeof(unsigned long long);
         HIP_TRY_CREATE(hipMalloc((void **)&e->stamps_dev, n));
@@ -354,11 +354,11 @@ static int run_stitch(JpegAmdEncoder *e, const ImageDesc &im, void *const *outs_
     // a fresh epoch per launch: granules of older launches never match (no zeroing between launches); the arrays are cleared
     // when the 14-bit tag wraps
     if (e->epoch >= 16383u) {
-        if (hipMemsetAsync(e->desc, 0, 3 * (size_t)e->max_wgs * sizeof(unsigned long long), stream) != hipSuccess) return (int)hipErrorUnknown;
+        if (hipMemsetAsync(e->desc, 0, 12 * (size_t)e->max_wgs * sizeof(uint32_t), stream) != hipSuccess) return (int)hipErrorUnknown;
         e->epoch = 0;
     }
     sa.epoch = ++e->epoch;
-    sa.desc_bits = e->desc; sa.desc_tail = e->desc + e->max_wgs; sa.desc_ff = e->desc + 2 * (size_t)e->max_wgs;
+    sa.desc = e->desc; sa.desc_ffx = e->desc + 4 * (size_t)e->max_wgs;
     sa.seg_syms = e->seg.syms; sa.seg_exact = e->seg.exact;
     for (int i = 0; i < im.batch; ++i) { sa.out[i] = (uint8_t *)outs_dev[i]; sa.out_size[i] = out_sizes_dev[i]; }
     sa.out_capacity = out_capacity; sa.stats = e->stats_dev; sa.status = &e->stats_dev->status;
@@ -479,7 +479,7 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
                                         void *stream_) {
     if (!e || !out_dev || !out_size_dev) return JPEGAMD_ERR_ARG;
     ImageDesc im;
-    int32_t rc = describe(e, img, &im);
+    int32_t rc = describe(e, img, &im, kSegTilesBatch);                 // whole images: k_stitch works on segments of 16 tiles
     if (rc) return rc;
     rc = prepare_constants(e, img, with_container != 0);
     if (rc) return rc;
@@ -510,14 +510,9 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
                                               void *stream_) {
     if (!e || !imgs || !outs_dev || !out_sizes_dev || count < 1 || count > kMaxBatch) return JPEGAMD_ERR_ARG;
     ImageDesc im;
-    int seg_tiles = count >= 4 ? kSegTilesBatch : kSegTiles;             // many pictures: longer segments (jpegamd_internal.h)
+    const int seg_tiles = kSegTilesBatch;                                // whole images: k_stitch works on segments of 16 tiles
     int32_t rc = describe(e, &imgs[0], &im, seg_tiles);
     if (rc) return rc;
-    if (seg_tiles != kSegTiles && (size_t)count * im.num_segs * seg_cap_words(seg_tiles) > e->words_cap) {   // (a geometry other than the context's own)
-        seg_tiles = kSegTiles;
-        rc = describe(e, &imgs[0], &im, seg_tiles);
-        if (rc) return rc;
-    }
     for (int i = 0; i < count; ++i) {
         const JpegAmdImage &g = imgs[i];
         if (!outs_dev[i] || !out_sizes_dev[i] || !g.pixels) return JPEGAMD_ERR_ARG;
@@ -527,8 +522,7 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
         im.batch_pixels[i] = (const uint8_t *)g.pixels;
         if ((((uintptr_t)g.pixels) & 3u) != 0) im.fast_ok = 0;
     }
-    if ((int64_t)count * im.num_tiles > e->max_tiles || (int64_t)count * im.num_segs > e->max_segs ||
-        (size_t)count * im.num_segs * seg_cap_words(seg_tiles) > e->words_cap) return JPEGAMD_ERR_TOO_LARGE;
+    if ((int64_t)count * im.num_tiles > e->max_tiles || (int64_t)count * im.num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
     im.batch = count;
     im.tile_end = count * im.num_tiles;
     im.seg_end = count * im.num_segs;

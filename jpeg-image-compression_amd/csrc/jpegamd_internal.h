@@ -177,9 +177,8 @@ int finalize_chunks(int num_segs);
 
 // k_stitch (jpegamd_stitch.hip): whole images -- the tiles' strings -> the finished entropy-coded segment in ONE pass (what
 // k_segment_merge + k_finalize do in two for the block-row shards of one image over several GPUs).
-// Hand-off granules between workgroups: bits 63..50 the launch epoch, 49..48 the status (1 = this workgroup's own value,
-// 2 = inclusive of every workgroup in front of it in the picture), 47..0 the value.  The arrays are zeroed when the context
-// is created and whenever the 14-bit epoch wraps; a granule of an older launch never matches the epoch.
+// Workgroups hand their numbers on in 16-byte granules tagged with the launch's 14-bit epoch (layout: jpegamd_stitch.hip); the
+// array is zeroed when the context is created and whenever the epoch wraps, so a granule of an older launch never matches.
 struct StitchArgs {
     const uint32_t *tile_head, *tile_over;
     const uint32_t *huff;           // [272] (len << 16) | code: AC by run/size symbol, then 16 DC sizes
@@ -188,7 +187,8 @@ struct StitchArgs {
     int32_t tiles_per_image;
     int32_t batch, wgs_per_image;   // grid = batch * wgs_per_image
     uint32_t epoch;                 // 1 .. 16383
-    unsigned long long *desc_bits, *desc_tail, *desc_ff;   // [batch * wgs_per_image] granules
+    uint32_t *desc;                 // [batch * wgs_per_image][4] granules
+    uint32_t *desc_ffx;             // [batch * wgs_per_image][8] a workgroup's 0xFF counts by byte phase in full (read when a granule's 8-bit counts saturated)
     uint32_t *seg_syms, *seg_exact; // [batch * num_segs] per-segment counters (summed on request)
     uint8_t *out[kMaxBatch];
     uint64_t out_capacity;          // of every output

@@ -26,75 +26,38 @@
 
 namespace jpegamd {
 
-#ifndef JPEGAMD_STITCH_WAVES
-#define JPEGAMD_STITCH_WAVES 8
-#endif
-constexpr int kStWaves = JPEGAMD_STITCH_WAVES;   // segments per workgroup
 constexpr int kStStripPieces = 130;              // 16-byte pieces of a wave's staging strip (15 + 2 x 1024 bytes at most)
 constexpr int kStCarry = 4;                      // window word j lives at index kStCarry + j; kStCarry - 1 holds the bits in front
 constexpr uint32_t kSpinLimit = 1u << 18;        // polls before a look-back gives up (status bit 2): a fraction of a second, not a hang
 
 typedef unsigned long long u64;
-typedef __attribute__((address_space(1))) u64 gu64;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((address_space(1))) uint32_t gu32;
 
-__device__ __forceinline__ u64 gran_pack(uint32_t epoch, uint32_t status, u64 value) { return ((u64)epoch << 50) | ((u64)status << 48) | value; }
-__device__ __forceinline__ void gran_store(u64 *p, u64 v) { __hip_atomic_store((gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 gran_load(const u64 *p) { return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-constexpr u64 kGranValue = (1ull << 48) - 1ull;
-
-// sum over the wave of a value below 2^48 (two 24-bit halves: each half's sum stays below 2^30)
-__device__ __forceinline__ u64 wave_sum_u48(u64 v) {
-    const uint32_t lo = (uint32_t)wave_sum_i32((int)((uint32_t)v & 0xFFFFFFu)), hi = (uint32_t)wave_sum_i32((int)(uint32_t)(v >> 24));
-    return ((u64)hi << 24) + lo;
+// ---- the hand-off granule: 16 bytes per workgroup, written by ONE store and read by ONE load, both write-through / L1-bypassing
+// (sc1).  AGGREGATE (status 1: what the workgroup's own segments add, whatever lies in front of it):
+//   d0  31..18 epoch, 17..16 status, 15..8 the workgroup's first 8 bits, 7..1 its last 7 bits, 0 "counts saturated"
+//   d1  31..24 check byte, 23..0 bits of the workgroup's segments
+//   d2, d3     for each byte phase p = 0..7 the workgroup's first bit may land on: the 0xFF bytes lying wholly inside the
+//              workgroup's bits, 8 bits each, saturated at 255 (then bit 0 of d0 is set and StitchArgs::desc_ffx holds them in full)
+// INCLUSIVE (status 2: everything from the picture's first bit to the workgroup's last):
+//   d0  epoch, status, 7..1 the stream's last 7 bits     d1 bits (low 32)     d2 0xFF bytes owned (low 32)
+//   d3  31..24 check byte, 23..12 bits (high 12), 11..0 0xFF bytes (high 12)
+// The check byte ties the four words to one store (a 16-byte store was never seen torn on gfx950, but nothing promises it).
+__device__ __forceinline__ uint32_t gran_check(uint32_t epoch, uint32_t x, uint32_t y) {
+    return (epoch + __builtin_amdgcn_sad_u8(x, 0u, 0u) + __builtin_amdgcn_sad_u8(y, 0u, 0u)) & 0xFFu;
 }
-
-// Exclusive prefix of workgroup g's value over the workgroups [0, g) of its picture (desc points at the picture's first
-// granule): the value of every predecessor back to the nearest INCLUSIVE one.  Called by one whole wave; the aggregate was
-// published (status 1) by publish_aggregate.  Leaves the inclusive value (status 2) behind for the workgroups that follow.
-__device__ __forceinline__ void publish_aggregate(u64 *desc, int g, uint32_t epoch, u64 mine, int lane) {
-    if (lane == 0) gran_store(desc + g, gran_pack(epoch, g == 0 ? 2u : 1u, mine));
+__device__ __forceinline__ bool gran_valid(const u32x4 &v, uint32_t epoch) {
+    const uint32_t st = (v[0] >> 16) & 3u;
+    if ((v[0] >> 18) != epoch || st == 0u) return false;
+    return st == 1u ? (v[1] >> 24) == gran_check(epoch, v[2], v[3]) : (v[3] >> 24) == gran_check(epoch, v[1], v[2]);
 }
-__device__ __forceinline__ u64 lookback(u64 *desc, int g, uint32_t epoch, u64 mine, int lane, uint32_t *status) {
-    if (g == 0) return 0ull;
-    u64 excl = 0;
-    int hi = g;                                  // predecessors [0, hi) still to be accounted for
-    uint32_t spins = 0;
-    for (;;) {
-        u64 v[4];
-        uint32_t ok = 0, inc = 0;                // bit k: granule k of this lane is valid / inclusive
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {            // lane l, granule k: predecessor hi - 1 - (4 l + k); beyond the picture's start: inclusive zero
-            const int idx = hi - 1 - (4 * lane + k);
-            v[k] = idx >= 0 ? gran_load(desc + idx) : gran_pack(epoch, 2u, 0ull);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t st = (uint32_t)(v[k] >> 48) & 3u;
-            const bool valid = (uint32_t)(v[k] >> 50) == epoch && st != 0u;
-            ok |= valid ? 1u << k : 0u;
-            inc |= (valid && st == 2u) ? 1u << k : 0u;
-        }
-        // the nearest inclusive granule: lowest lane that has one, lowest k inside it
-        const u64 mi = __ballot(inc != 0u);
-        const int fl = mi ? __ffsll((long long)mi) - 1 : 64;                               // lanes below fl need all four valid
-        const uint32_t inc_fl = fl < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)inc, fl) : 0u;
-        const int fk = fl < 64 ? __ffs((int)inc_fl) - 1 : 4;                               // lane fl needs granules 0 .. fk
-        const uint32_t need = lane < fl ? 15u : (lane == fl ? (2u << fk) - 1u : 0u);
-        if (__ballot((ok & need) != need) != 0ull) {                                       // somebody in front has not published yet
-            if (++spins > kSpinLimit) { if (lane == 0) atomicOr(status, 4u); return excl; }
-            __builtin_amdgcn_s_sleep(2);
-            continue;
-        }
-        u64 part = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) part += ((need >> k) & 1u) ? (v[k] & kGranValue) : 0ull;
-        // (a lane's four values: below 2^50; split the sum so that both halves stay inside 32 bits)
-        excl += wave_sum_u48(part & kGranValue) + (wave_sum_u48(part >> 48) << 48);
-        if (mi) break;
-        hi -= 256;
-    }
-    if (lane == 0) gran_store(desc + g, gran_pack(epoch, 2u, (excl + mine) & kGranValue));
-    return excl;
+// a byte straddling the boundary between a string ending in `tail7` and one starting with `first8` (left-aligned, zeros
+// behind a string shorter than 8 bits), `a` of its bits in front of the boundary: is it 0xFF?
+__device__ __forceinline__ uint32_t straddle_ff(uint32_t tail7, uint32_t first8, uint32_t a) {
+    const uint32_t tail_ones = (uint32_t)__builtin_ctz(~(tail7 & 0x7Fu));          // 0..7
+    const uint32_t lead_ones = (uint32_t)__clz(~(first8 << 24));                   // 0..8
+    return (a != 0u && tail_ones >= a && lead_ones >= 8u - a) ? 1u : 0u;
 }
 
 // last min(nbits, 7) bits of a bit string of nbits bits whose words start at w (right-aligned; zeros above them)
@@ -108,19 +71,30 @@ __device__ __forceinline__ uint32_t tail7_of(const uint32_t *w, uint32_t nbits) 
 __device__ __forceinline__ uint32_t tail7_join(uint32_t before, uint32_t tail, uint32_t nbits) {
     return nbits >= 7u ? tail : ((before << nbits) | tail) & 0x7Fu;
 }
+// 0xFF bytes by byte phase (jpegamd_entropy.hip has the same census): for the word `cur` followed by `nxt` (MSB-first), bit
+// (31 - o) of the result is set when the 8 stream bits from offset o of `cur` are all ones.
+__device__ __forceinline__ uint32_t st_ones8_starts(uint32_t cur, uint32_t nxt) {
+    uint32_t hi = cur & __builtin_amdgcn_alignbit(cur, nxt, 31u), lo = nxt & (nxt << 1);
+    hi &= __builtin_amdgcn_alignbit(hi, lo, 30u); lo &= lo << 2;
+    hi &= __builtin_amdgcn_alignbit(hi, lo, 28u);
+    return hi;
+}
 
-template <int kTiles>
+template <int kTiles, int kStWaves>
 __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
     constexpr int kBuf = 64 * kTiles;                             // bit window per wave (words): a typical segment is ~23 words per tile
     constexpr int kLanesPerTile = 64 / kTiles;                    // lanes that share a tile's string in the lane-parallel placement
     constexpr int kStepWords = kLanesPerTile * 4;                 // words of every tile's string moved per step
     constexpr uint32_t kPartBits = (uint32_t)(kBuf - 8) * 32u;    // a part's bits: the window, less a margin for the placement's trailing ds_or
     constexpr uint32_t kPieceWords = 128;                         // words of one tile's string moved per step of the tile-by-tile placement
+    static_assert(kStWaves <= 16, "the waves' numbers are scanned in one DPP row");
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kStWaves][kStCarry + kBuf + 12];
     __shared__ __attribute__((aligned(16))) uint32_t s_strip[kStWaves][4 * kStStripPieces];
-    __shared__ uint32_t s_bits[kStWaves], s_tail[kStWaves], s_ff[kStWaves];
-    __shared__ u64 s_b0, s_ff0;
-    __shared__ uint32_t s_prevtail;
+    // what a wave tells the workgroup about its segment: bits, first 8 / last 7 bits, 0xFF bytes inside it by byte phase ...
+    __shared__ uint32_t s_bits[kStWaves], s_first8[kStWaves], s_last7[kStWaves], s_ffc[kStWaves][8];
+    // ... and what wave 0 tells it back once the look-back is through: stream bit offset, stuffed bytes in front, owned 0xFF bytes, the 7 bits in front
+    __shared__ u64 s_b0s[kStWaves], s_ffoff[kStWaves];
+    __shared__ uint32_t s_myff[kStWaves], s_tailin[kStWaves];
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), tid = (int)threadIdx.x;
     const int image = a.batch > 1 ? (int)blockIdx.x / a.wgs_per_image : 0;
     const int g = (int)blockIdx.x - image * a.wgs_per_image;      // workgroup inside its picture
@@ -128,7 +102,6 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
     const bool have = s < a.num_segs;                             // (a wave without a segment walks on with no tiles: the workgroup meets at barriers)
     const int sc = have ? s : a.num_segs - 1;
     uint32_t *const wv = &s_win[wave][kStCarry];                  // wv[-1]: the (up to 7) stream bits in front of the window's first bit
-    u64 *const d_bits = a.desc_bits + ((int)blockIdx.x - g), *const d_tail = a.desc_tail + ((int)blockIdx.x - g), *const d_ff = a.desc_ff + ((int)blockIdx.x - g);
     uint8_t *const out = a.out[image];
     const u64 out_capacity = a.out_capacity;
 
@@ -195,23 +168,11 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
     const uint32_t nwords_t = (rbits + 31u) >> 5;                                  // lane t: words of tile t's string
     const uint32_t max_words = (uint32_t)wave_max_u32(nwords_t);
     const bool single = seg_bits <= kPartBits && max_words <= (uint32_t)kTileHeadStr;   // (uniform) everything fits the window: ONE part, placed once
-    if (lane == 0) {
-        s_bits[wave] = seg_bits;
-        if (have) {
-            const size_t sg = (size_t)image * (size_t)a.num_segs + (size_t)s;
-            a.seg_syms[sg] = (uint32_t)seg_syms;
-            a.seg_exact[sg] = (uint32_t)seg_exact;
-            if (any_bad) atomicOr(a.status, 2u);
-        }
-    }
-    __syncthreads();                                                               // ---- barrier 1: the workgroup's bit counts
-
-    // ---- 2. publish the workgroup's bits; place the strings -----------------------------------------------------------------
-    u64 wg_bits = 0;
-    if (wave == 0) {
-        const uint32_t b = lane < kStWaves ? s_bits[lane] : 0u;
-        wg_bits = (u64)(uint32_t)wave_sum_i32((int)(b & 0xFFFFu)) + ((u64)(uint32_t)wave_sum_i32((int)(b >> 16)) << 16);
-        publish_aggregate(d_bits, g, a.epoch, wg_bits, lane);
+    if (lane == 0 && have) {
+        const size_t sg = (size_t)image * (size_t)a.num_segs + (size_t)s;
+        a.seg_syms[sg] = (uint32_t)seg_syms;
+        a.seg_exact[sg] = (uint32_t)seg_exact;
+        if (any_bad) atomicOr(a.status, 2u);
     }
 
     // One tile's string word j (head, then the sparse reservation), for the slow paths.
@@ -336,72 +297,6 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
         }
     };
 
-    uint32_t seg_tail = 0;                                            // last min(seg_bits, 7) bits of the segment
-    if (single) {
-        if (ntiles > 0) place_all();
-        seg_tail = tail7_of(wv, seg_bits);
-    } else {
-        // the tail of a long segment without placing it: the last bits of [DC symbol | string] of the last tiles
-        uint32_t got = 0;
-        for (int t = ntiles - 1; t >= 0 && got < 7u; --t) {
-            const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)rbits, t);
-            if (sb) {
-                const uint32_t take = min(7u - got, sb), pos = sb - take, j = pos >> 5, sh = pos & 31u;
-                bool o0, o1;
-                const int f0 = str_word_off(t, j, o0), f1 = str_word_off(t, j + 1u, o1);
-                const uint32_t x0 = o0 ? __builtin_amdgcn_raw_buffer_load_b32(orsrc, f0, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(hrsrc, f0, 0, 0);
-                const uint32_t x1 = (pos + take > 32u * (j + 1u)) ? (o1 ? __builtin_amdgcn_raw_buffer_load_b32(orsrc, f1, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(hrsrc, f1, 0, 0)) : 0u;
-                const u64 win = ((u64)x0 << 32) | x1;
-                seg_tail |= (uint32_t)((win << sh) >> (64u - take)) << got;
-                got += take;
-            }
-            const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)dclen, t), ds = (uint32_t)__builtin_amdgcn_readlane((int)dcsym, t);
-            if (got < 7u && dl) {
-                const uint32_t take = min(7u - got, dl);
-                seg_tail |= (ds & ((1u << take) - 1u)) << got;
-                got += take;
-            }
-        }
-    }
-    if (lane == 0) s_tail[wave] = seg_tail;
-    __syncthreads();                                                               // ---- barrier 2: the segments' tails
-
-    // ---- 3. bit offset of the workgroup (look-back), the bits in front of it ------------------------------------------------
-    // the last 7 bits of the stream in front of segment `upto` of this workgroup, given those in front of the workgroup
-    const auto tail_before = [&](int upto, uint32_t before_wg) -> uint32_t {
-        uint32_t t = before_wg;
-        for (int j = 0; j < upto; ++j) t = tail7_join(t, s_tail[j], s_bits[j]);
-        return t;
-    };
-    if (wave == 0) {
-        const uint32_t wg_tail = tail_before(kStWaves, 0u);                        // (valid as 7 bits whenever another workgroup follows: 16 segments >= 96 bits)
-        if (lane == 0) gran_store(d_tail + g, gran_pack(a.epoch, 1u, (u64)wg_tail));
-        const u64 b0 = lookback(d_bits, g, a.epoch, wg_bits, lane, a.status);
-        uint32_t pt = 0;
-        if (g > 0) {
-            uint32_t spins = 0;
-            for (;;) {
-                const u64 v = gran_load(d_tail + g - 1);
-                if ((uint32_t)(v >> 50) == a.epoch && ((v >> 48) & 3ull) != 0ull) { pt = (uint32_t)v & 0x7Fu; break; }
-                if (++spins > kSpinLimit) { if (lane == 0) atomicOr(a.status, 4u); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        if (lane == 0) { s_b0 = b0; s_prevtail = pt; }
-    }
-    __syncthreads();                                                               // ---- barrier 3: the workgroup's bit offset
-
-    // ---- 4. per segment: byte phase, owned 0xFF bytes ------------------------------------------------------------------------
-    uint32_t pre_bits;
-    {
-        const uint32_t b = lane < kStWaves ? s_bits[lane] : 0u;
-        const uint32_t incl = half_incl_scan_dpp(b);                               // kStWaves <= 16: one DPP row
-        pre_bits = (uint32_t)__builtin_amdgcn_readlane((int)(incl - b), wave);
-    }
-    static_assert(kStWaves <= 16, "the waves' numbers are scanned in one DPP row");
-    const u64 b0s = s_b0 + pre_bits;                                               // stream bit offset of the segment in its picture
-    const uint32_t tail_in = tail_before(wave, s_prevtail);                        // the 7 stream bits in front of the segment
-
     // 0xFF bytes among the `nown` owned bytes of what the window holds, `lead` borrowed bits in wv[-1]'s low end.
     // Owned byte q = stream bits [8 q - lead, 8 q - lead + 8) of the window.
     const auto group_words = [&](uint32_t idx, uint32_t lead, uint32_t (&v)[4]) {  // the 16 owned bytes 16 idx .. + 15, big-endian in 4 words
@@ -434,49 +329,251 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
         return (uint32_t)wave_sum_i32((int)c);
     };
 
-    uint32_t my_ff = 0;
-    if (have) {
-        if (single) {
-            const uint32_t lead = (uint32_t)(b0s & 7ull);
-            if (lane == 0) wv[-1] = tail_in;
-            my_ff = census(lead, (uint32_t)(((b0s + seg_bits) >> 3) - (b0s >> 3)));
-        } else {
-            int pt = 0; uint32_t pw = 0, tl = tail_in;
-            u64 pos = b0s;
-            bool fresh = true;                                                     // the window is still zero from the start
-            while (pt < ntiles) {
-                const Part p = next_part(pt, pw);
-                if (!fresh) zero_window();
-                fresh = false;
-                place_part(p);
-                if (lane == 0) wv[-1] = tl;
-                my_ff += census((uint32_t)(pos & 7ull), (uint32_t)(((pos + p.bits) >> 3) - (pos >> 3)));
-                tl = tail7_join(tl, tail7_of(wv, p.bits), p.bits);
-                pos += p.bits;
-                advance(p, pt, pw);
+    // ---- 2. the strings go into the window; the segment's numbers -----------------------------------------------------------
+    // 0xFF bytes lying wholly inside the segment for each byte phase p its first bit may land on: a byte starts at bit i of the
+    // segment when (i + p) % 8 == 0.  `at` = bit offset of the window's first bit in the segment (parts).
+    uint32_t ffc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    bool any_ff = false;
+    const auto census8 = [&](uint32_t nbits, uint32_t at) {
+        const uint32_t nw = (nbits + 31u) >> 5;
+        for (uint32_t i0 = 0; i0 < nw; i0 += 64u) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            uint32_t cw = 0, nx = 0;
+            if (i < nw) { cw = wv[i]; nx = wv[i + 1]; }
+            const uint32_t m = st_ones8_starts(cw, nx);       // (the window is zero behind the string: no run of ones reaches beyond it)
+            if (__ballot(m != 0u) != 0ull) {
+                any_ff = true;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) ffc[p] += (uint32_t)__popc(m & (0x80808080u >> ((16u - (uint32_t)p - (at & 7u)) & 7u)));
             }
         }
+    };
+    uint32_t seg_tail = 0, seg_first8 = 0;                            // last min(seg_bits, 7) bits (right-aligned), first 8 (left-aligned, zeros behind a shorter string)
+    uint32_t xff = 0;                                                 // lane p < 8: bytes straddling two parts that are 0xFF at phase p
+    if (single) {
+        if (ntiles > 0) place_all();
+        seg_tail = tail7_of(wv, seg_bits);
+        seg_first8 = wv[0] >> 24;
+        census8(seg_bits, 0u);
+    } else {
+        int pt = 0; uint32_t pw = 0, at = 0, got8 = 0;
+        bool fresh = true;                                            // the window is still zero from the start
+        while (pt < ntiles) {
+            const Part p = next_part(pt, pw);
+            if (!fresh) zero_window();
+            fresh = false;
+            place_part(p);
+            census8(p.bits, at);
+            const uint32_t f8 = wv[0] >> 24;
+            if (at) xff += straddle_ff(seg_tail, f8, ((uint32_t)lane + at) & 7u);      // (zeros in front of the segment: a byte that starts before it is not inside it)
+            if (got8 < 8u) { seg_first8 |= (f8 >> got8) & 0xFFu; got8 += min(p.bits, 8u - got8); }
+            seg_tail = tail7_join(seg_tail, tail7_of(wv, p.bits), p.bits);
+            at += p.bits;
+            advance(p, pt, pw);
+        }
+        zero_window();                                                // (the output pass places the parts again)
     }
-    if (lane == 0) s_ff[wave] = my_ff;
-    __syncthreads();                                                               // ---- barrier 4: the segments' 0xFF counts
+    {
+        uint32_t mine = lane < 8 ? xff : 0u;                          // lane p < 8 ends up with the count of phase p
+        if (any_ff) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint32_t t = (uint32_t)wave_sum_i32((int)ffc[p]);
+                if (lane == p) mine += t;
+            }
+        }
+        if (lane < 8) s_ffc[wave][lane] = mine;
+        if (lane == 0) { s_bits[wave] = seg_bits; s_first8[wave] = seg_first8; s_last7[wave] = seg_tail; }
+    }
+    __syncthreads();                                                  // ---- barrier 1: every segment's numbers
 
+    // ---- 3. wave 0: the workgroup's aggregate goes out; its offsets come from the workgroups in front (look-back) ------------
     if (wave == 0) {
-        const uint32_t f = lane < kStWaves ? s_ff[lane] : 0u;
-        const u64 wg_ff = (u64)(uint32_t)wave_sum_i32((int)(f & 0xFFFFu)) + ((u64)(uint32_t)wave_sum_i32((int)(f >> 16)) << 16);
-        publish_aggregate(d_ff, g, a.epoch, wg_ff, lane);
-        const u64 f0 = lookback(d_ff, g, a.epoch, wg_ff, lane, a.status);
-        if (lane == 0) s_ff0 = f0;
+        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(a.desc + 4 * (size_t)((int)blockIdx.x - g), 0, a.wgs_per_image * 16, 0x00020000);
+        uint32_t *const ffx_mine = a.desc_ffx + 8 * (size_t)blockIdx.x;
+        const uint32_t P = (uint32_t)lane & 7u;
+        // aggregate: lane P (0..7) walks the segments with the workgroup's first bit at phase P
+        uint32_t agg = 0, wg_bits = 0, wg_tail0 = 0, wg_first8 = 0, got8 = 0;
+        for (int j = 0; j < kStWaves; ++j) {
+            const uint32_t bj = s_bits[j], ph = (P + wg_bits) & 7u;
+            uint32_t c = s_ffc[j][ph];
+            if (j > 0) c += straddle_ff(wg_tail0, s_first8[j], ph);      // (the byte straddling the workgroup's start is the look-back's)
+            agg += bj ? c : 0u;
+            if (got8 < 8u) { wg_first8 |= (s_first8[j] >> got8) & 0xFFu; got8 += min(bj, 8u - got8); }
+            wg_tail0 = tail7_join(wg_tail0, s_last7[j], bj);
+            wg_bits += bj;
+        }
+        const bool esc = __ballot(lane < 8 && agg > 255u) != 0ull;
+        const uint32_t sat = min(agg, 255u);
+        uint32_t d2 = 0, d3 = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            d2 |= (uint32_t)__builtin_amdgcn_readlane((int)sat, p) << (8 * p);
+            d3 |= (uint32_t)__builtin_amdgcn_readlane((int)sat, p + 4) << (8 * p);
+        }
+        if (esc) {                                                    // (rare: dense content) the counts in full, in memory before the granule that points at them
+            if (lane < 8) __hip_atomic_store((gu32 *)(ffx_mine + lane), agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const auto store_gran = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+            const u32x4 gv = {x0, x1, x2, x3};
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b128(gv, drsrc, g * 16, 0, 16 /*sc1: write-through*/);
+        };
+        const auto store_inclusive = [&](u64 bits, u64 ff, uint32_t last7) {
+            const uint32_t x1 = (uint32_t)bits, x2 = (uint32_t)ff;
+            store_gran((a.epoch << 18) | (2u << 16) | (last7 << 1), x1, x2,
+                       (gran_check(a.epoch, x1, x2) << 24) | (((uint32_t)(bits >> 32) & 0xFFFu) << 12) | ((uint32_t)(ff >> 32) & 0xFFFu));
+        };
+        u64 B0 = 0, FF0 = 0;
+        uint32_t prevtail = 0;
+        if (g > 0) {
+            store_gran((a.epoch << 18) | (1u << 16) | (wg_first8 << 8) | (wg_tail0 << 1) | (esc ? 1u : 0u), (gran_check(a.epoch, d2, d3) << 24) | wg_bits, d2, d3);
+#ifndef JPEGAMD_ST_NO_LOOKBACK     // (timing-only builds skip the wait: wrong offsets, every write still inside the output)
+            // Round r reads the predecessors hi - 1 .. hi - 256 (lane l, k = 0..3: hi - 1 - (4 l + k)), nearest first, until one of
+            // them is INCLUSIVE; workgroup 0's always is.
+            u32x4 v[4];
+            const auto load_round = [&](int hi) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = hi - 1 - (4 * lane + k);
+                    if (idx >= 0) v[k] = __builtin_amdgcn_raw_buffer_load_b128(drsrc, idx * 16, 0, 16 /*sc1*/);
+                    else { const u32x4 z = {(a.epoch << 18) | (2u << 16), 0u, 0u, gran_check(a.epoch, 0u, 0u) << 24}; v[k] = z; }   // in front of the picture: nothing
+                }
+            };
+            uint32_t ok = 0, inc = 0;
+            int fl = 64, fk = 4;                                    // the nearest inclusive granule of the round: lane fl, k = fk
+            const auto classify = [&]() -> bool {                   // -> every granule up to the nearest inclusive one is valid
+                ok = 0; inc = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool valid = gran_valid(v[k], a.epoch);
+                    ok |= valid ? 1u << k : 0u;
+                    inc |= (valid && ((v[k][0] >> 16) & 3u) == 2u) ? 1u << k : 0u;
+                }
+                const u64 mi = __ballot(inc != 0u);
+                fl = mi ? __ffsll((long long)mi) - 1 : 64;
+                const uint32_t inc_fl = fl < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)inc, fl) : 0u;
+                fk = fl < 64 ? __ffs((int)inc_fl) - 1 : 4;
+                const uint32_t need = lane < fl ? 15u : (lane == fl ? (2u << fk) - 1u : 0u);
+                return __ballot((ok & need) != need) == 0ull;
+            };
+            const auto sum64 = [&](u64 x) -> u64 {                  // wave sum of values below 2^40
+                return (u64)(uint32_t)wave_sum_i32((int)((uint32_t)x & 0xFFFFFu)) + ((u64)(uint32_t)wave_sum_i32((int)(uint32_t)(x >> 20)) << 20);
+            };
+            const auto agg_bits = [&](int k) -> uint32_t {          // bits of granule k when it is an aggregate in front of the inclusive one
+                const bool nearer = lane < fl || (lane == fl && k < fk);
+                return nearer ? v[k][1] & 0xFFFFFFu : 0u;
+            };
+            const auto incl_sel = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) -> uint32_t {      // a word of the round's inclusive granule (fl < 64)
+                const uint32_t x = fk == 0 ? x0 : fk == 1 ? x1 : fk == 2 ? x2 : x3;
+                return (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
+            };
+#define JPEGAMD_INCL_WORD(W) incl_sel(v[0][W], v[1][W], v[2][W], v[3][W])
+            // phase 1: the bit offset.  (A sum: no order needed.)
+            int hi = g, rounds = 0;
+            uint32_t spins = 0;
+            bool failed = false;
+            for (;;) {
+                load_round(hi);
+                if (!classify()) {
+                    if (++spins > kSpinLimit) { failed = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                B0 += sum64((u64)agg_bits(0) + agg_bits(1) + agg_bits(2) + agg_bits(3));
+                ++rounds;
+                if (fl < 64) { B0 += (u64)JPEGAMD_INCL_WORD(1) | ((u64)((JPEGAMD_INCL_WORD(3) >> 12) & 0xFFFu) << 32); break; }
+                hi -= 256;
+            }
+            // phase 2: the 0xFF bytes in front, walking from the nearest workgroup again: with the bit offset known every
+            // predecessor's byte phase is, and with it the count it contributes.  (A granule may have turned inclusive since phase
+            // 1: the walk then simply ends earlier.)
+            hi = g;
+            uint32_t near_bits = 0;                                 // bits of the predecessors already walked (mod 2^32: phases need 3 bits)
+            bool first_round = true;
+            while (!failed) {
+                if (!(first_round && rounds == 1)) {                // (one round: phase 1's registers are the snapshot)
+                    load_round(hi);
+                    if (!classify()) {
+                        if (++spins > kSpinLimit) { failed = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                }
+                if (first_round) prevtail = ((uint32_t)__builtin_amdgcn_readlane((int)v[0][0], 0) >> 1) & 0x7Fu;
+                first_round = false;
+                // the workgroup in front of the round's farthest one, for lane 63's last granule
+                uint32_t far_tail = 0;
+                if (fl == 64 && hi - 257 >= 0) {
+                    const u32x4 e = __builtin_amdgcn_raw_buffer_load_b128(drsrc, (hi - 257) * 16, 0, 16);
+                    far_tail = (e[0] >> 1) & 0x7Fu;              // (valid: every workgroup publishes its aggregate before it looks back, and the round was complete)
+                    if (!gran_valid(e, a.epoch)) { if (++spins > kSpinLimit) { failed = true; break; } __builtin_amdgcn_s_sleep(2); continue; }
+                }
+                uint32_t bk[4], cum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { bk[k] = agg_bits(k); cum += bk[k]; }
+                const uint32_t lane_incl = wave_incl_scan_u32(cum);
+                const uint32_t round_bits = (uint32_t)__builtin_amdgcn_readlane((int)lane_incl, 63);
+                uint32_t before = near_bits + lane_incl - cum;      // bits of the predecessors nearer than my granule 0
+                const uint32_t next_tail0 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) * 4, (int)((v[0][0] >> 1) & 0x7Fu));   // last 7 bits of lane + 1's granule 0
+                const bool any_esc = __ballot(((v[0][0] | v[1][0] | v[2][0] | v[3][0]) & 1u) != 0u) != 0ull;
+                u64 contrib = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool nearer = lane < fl || (lane == fl && k < fk);
+                    before += bk[k];
+                    const uint32_t ph = ((uint32_t)B0 - before) & 7u;                       // byte phase of this workgroup's first bit
+                    uint32_t c = ((ph & 4u ? v[k][3] : v[k][2]) >> (8u * (ph & 3u))) & 0xFFu;
+                    if (any_esc && nearer && (v[k][0] & 1u)) {                              // saturated: the count in full
+                        const int idx = hi - 1 - (4 * lane + k);
+                        c = __hip_atomic_load((gu32 *)(a.desc_ffx + 8 * (size_t)((int)blockIdx.x - g + idx) + ph), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const uint32_t tail_far = k < 3 ? (v[k < 3 ? k + 1 : 3][0] >> 1) & 0x7Fu : (lane == 63 ? far_tail : next_tail0);
+                    c += straddle_ff(tail_far, (v[k][0] >> 8) & 0xFFu, ph);
+                    contrib += nearer ? c : 0u;
+                }
+                FF0 += sum64(contrib);
+                if (fl < 64) { FF0 += (u64)JPEGAMD_INCL_WORD(2) | ((u64)(JPEGAMD_INCL_WORD(3) & 0xFFFu) << 32); break; }
+                near_bits += round_bits;
+                hi -= 256;
+            }
+            if (failed && lane == 0) atomicOr(a.status, 4u);
+#undef JPEGAMD_INCL_WORD
+#endif
+        }
+        // every segment's offsets (lane j: segment j of the workgroup), and the inclusive granule for the workgroups that follow
+        uint32_t pre = 0, tb = prevtail, bj = 0, cj = 0;
+        {
+            uint32_t run = 0;
+            for (int j = 0; j < kStWaves; ++j) {                    // (uniform walk; lane j keeps what belongs to segment j)
+                const uint32_t b = s_bits[j];
+                if (lane == j) { pre = run; bj = b; }
+                run += b;
+            }
+            for (int j = 0; j < lane && j < kStWaves; ++j) tb = tail7_join(tb, s_last7[j], s_bits[j]);
+        }
+        if (lane < kStWaves && bj) {
+            const uint32_t ph = (uint32_t)((B0 + pre) & 7ull);
+            cj = s_ffc[lane][ph] + straddle_ff(tb, s_first8[lane], ph);
+        }
+        const uint32_t cincl = half_incl_scan_dpp(lane < kStWaves ? cj : 0u);
+        const uint32_t wg_ff = (uint32_t)__builtin_amdgcn_readlane((int)cincl, kStWaves - 1);
+        if (lane < kStWaves) {
+            s_b0s[lane] = B0 + pre;
+            s_ffoff[lane] = FF0 + (cincl - cj);
+            s_myff[lane] = cj;
+            s_tailin[lane] = tb;
+        }
+        uint32_t tail_end_wg = prevtail;
+        for (int j = 0; j < kStWaves; ++j) tail_end_wg = tail7_join(tail_end_wg, s_last7[j], s_bits[j]);
+        store_inclusive(B0 + wg_bits, FF0 + wg_ff, tail_end_wg);
     }
-    __syncthreads();                                                               // ---- barrier 5: stuffed bytes in front of the workgroup
+    __syncthreads();                                                  // ---- barrier 2: every segment's offsets
     if (!have) return;                                                             // no workgroup-wide synchronisation below
 
-    // ---- 5. the owned bytes go out --------------------------------------------------------------------------------------------
-    uint32_t ff_in;
-    {
-        const uint32_t f = lane < kStWaves ? s_ff[lane] : 0u;
-        const uint32_t incl = half_incl_scan_dpp(f);
-        ff_in = (uint32_t)__builtin_amdgcn_readlane((int)(incl - f), wave);
-    }
+    // ---- 4. the owned bytes go out ------------------------------------------------------------------------------------------
+    const u64 b0s = s_b0s[wave], ffoff = s_ffoff[wave];             // stream bit offset of the segment; stuffed bytes in front of it
+    const uint32_t my_ff = s_myff[wave], tail_in = s_tailin[wave];   // 0xFF bytes it owns; the 7 stream bits in front of it
     bool overflow = false;
     uint8_t *const strip = reinterpret_cast<uint8_t *>(&s_strip[wave][0]);
     u32x4 *const strip16 = reinterpret_cast<u32x4 *>(&s_strip[wave][0]);
@@ -567,10 +664,11 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
         if ((uint32_t)lane < fill && !(first && (uint32_t)lane < fill0)) gdst[lane] = strip[lane];     // what is left of the last piece
     };
 
-    const u64 base0 = (u64)a.prefix_len + (b0s >> 3) + s_ff0 + ff_in;               // where the segment's first owned byte goes
+    const u64 base0 = (u64)a.prefix_len + (b0s >> 3) + ffoff;                        // where the segment's first owned byte goes
     uint32_t tail_end = tail_in;                                                   // the 7 stream bits in front of the segment's end
     if (single) {
         const uint32_t lead = (uint32_t)(b0s & 7ull);
+        if (lane == 0) wv[-1] = tail_in;
         emit(lead, (uint32_t)(((b0s + seg_bits) >> 3) - (b0s >> 3)), base0, my_ff);
         tail_end = tail7_join(tail_in, seg_tail, seg_bits);
     } else {
@@ -594,7 +692,7 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
 
     if (s == a.num_segs - 1 && lane == 0) {
         const u64 b1 = b0s + seg_bits;
-        u64 end = (u64)a.prefix_len + (b1 >> 3) + s_ff0 + ff_in + my_ff;
+        u64 end = (u64)a.prefix_len + (b1 >> 3) + ffoff + my_ff;
         const uint32_t rem = (uint32_t)(b1 & 7ull);
         bool ok = true;
         if (rem) {                                              // zero-padded flush (huffman.c:65-81)
@@ -610,21 +708,24 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stitch(const StitchArgs a) {
         if (image == a.batch - 1) {
             a.stats->out_size = end;
             a.stats->total_bits = b1;
-            a.stats->total_ff = s_ff0 + ff_in + my_ff;
+            a.stats->total_ff = ffoff + my_ff;
         }
     }
 }
 
+// Segments of 16 tiles, eight per workgroup: an 8192^2 picture is 2 048 segments = 256 workgroups, so every look-back is ONE round of
+// four granules per lane.  (Measured: 8-tile segments with sixteen waves per workgroup 15.7 us per single 8192^2 picture against
+// 13.8; sixteen waves per workgroup at eight pictures per launch 79 us against 57 -- profiles/r04_notes_experiments.txt.)
+#ifndef JPEGAMD_ST_WAVES
+#define JPEGAMD_ST_WAVES 8
+#endif
+constexpr int kStWaves = JPEGAMD_ST_WAVES;
 int launch_stitch(const StitchArgs &a, void *stream, void *const *ev) {
     if (a.wgs_per_image <= 0 || a.batch <= 0) return 0;
-    const dim3 grid((unsigned)(a.wgs_per_image * a.batch)), block(64 * kStWaves);
-    if (a.seg_tiles == kSegTilesBatch) {
-        if (ev) hipExtLaunchKernelGGL(k_stitch<kSegTilesBatch>, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
-        else hipLaunchKernelGGL(k_stitch<kSegTilesBatch>, grid, block, 0, (hipStream_t)stream, a);
-    } else {
-        if (ev) hipExtLaunchKernelGGL(k_stitch<kSegTiles>, grid, block, 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
-        else hipLaunchKernelGGL(k_stitch<kSegTiles>, grid, block, 0, (hipStream_t)stream, a);
-    }
+    if (a.seg_tiles != kSegTilesBatch) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)(a.wgs_per_image * a.batch));
+    if (ev) hipExtLaunchKernelGGL((k_stitch<kSegTilesBatch, kStWaves>), grid, dim3(64 * kStWaves), 0, (hipStream_t)stream, (hipEvent_t)ev[0], (hipEvent_t)ev[1], 0, a);
+    else hipLaunchKernelGGL((k_stitch<kSegTilesBatch, kStWaves>), grid, dim3(64 * kStWaves), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
 int stitch_workgroups(int num_segs) { return (num_segs + kStWaves - 1) / kStWaves; }
