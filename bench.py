@@ -19,8 +19,8 @@ Workloads (`--workload`, default `auto`):
              distinct seeds (tests/golden/batch4096.json holds the compiled reference's answers for all 64); every finished
              bitstream collected at rank 0 by RCCL (N = 1: `--force-gather`, a one-rank group).
 Reference quantisation table (Q=50) unless --quality says otherwise; pixel rows resident in HBM; output = complete
-JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_encode -> k_stitch) over the
-step's images, on one HIP stream by default (`--streams`: k_tile_encode is a persistent kernel that fills the GPU; launches on
+JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_encode -> k_segment_merge -> k_finalize; `--pipeline stitch`:
+k_tile_encode -> k_stitch, the single-pass kernel the library itself takes for 16384^2-class pictures) over the step's images, on one HIP stream by default (`--streams`: k_tile_encode is a persistent kernel that fills the GPU; launches on
 several streams queue behind each other's workgroups and were measured slower); every step is a complete encode.  With N > 1 every rank
 encodes its own images (weak scaling, no data-path collective inside the encode) and the finished bitstreams are
 collected at rank 0 with one asynchronous RCCL gather per `--gather-every` images
@@ -28,7 +28,7 @@ collected at rank 0 with one asynchronous RCCL gather per `--gather-every` image
 
 Extra objects on the JSON line:
   "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes of ONE launch (BMP rows read + JFIF
-                  bytes written, per image x images_per_launch) / SUM of the two kernels' durations / 8 TB/s.  Durations are
+                  bytes written, per image x images_per_launch) / SUM of the kernels' durations / 8 TB/s.  Durations are
                   HIP-event timed inside this run through the C-ABI's event ring -- every kernel launched with its own begin / end
                   events on the stream it runs on (a kernel's own duration, as a kernel trace shows it) -- in SEPARATE single-stream
                   passes behind the timed region, whose own launches carry no events: once right behind the region (`sustained`) and
@@ -76,6 +76,8 @@ def parse_args():
     ap.add_argument("--images-per-launch", type=int, default=0, choices=[0, 1, 2, 4, 8, 16, 32],
                     help="images coded by ONE launch of each kernel (jpegamd_encode_batch_async); 0 = 8 for image8192 (8 images per step), "
                          "min(32, images per rank) for batch4096")
+    ap.add_argument("--pipeline", choices=["auto", "pair", "stitch"], default="auto",
+                    help="kernels behind k_tile_encode (jpegamd_encoder_set_pipeline): k_segment_merge + k_finalize, or the single-pass k_stitch")
     ap.add_argument("--roofline-idle-ms", type=float, default=250.0, help="idle time in front of the second single-stream roofline pass")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (one encoder context each) the launches alternate over.  One by default: k_tile_encode is a "
@@ -229,6 +231,9 @@ def main():
         nimg = len(inputs)
         nstreams = max(1, args.streams)
         encs = [jpegamd.Encoder(w, B * ((h + 7) // 8 * 8)) for _ in range(nstreams)]
+        if args.pipeline != "auto":
+            for e in encs:
+                e.set_pipeline({"pair": jpegamd.PIPELINE_PAIR, "stitch": jpegamd.PIPELINE_STITCH}[args.pipeline])
         cap = 4096 + w * h // 2 if args.kind != 1 and args.quality <= 75 else 4096 + 2 * w * h     # >10x the typical photo-like output
         nbuf = max(2 * nstreams * B, nimg, B + 1)
         outs = [torch.empty(cap, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
@@ -404,7 +409,7 @@ def main():
 
         if primary:
             h_tr, h_en, h_pk, _ = single_stream_pass(B)
-            sustained = {"transform_us": round(h_tr / 1e3, 2), "stitch_us": round(h_pk / 1e3, 2),
+            sustained = {"transform_us": round(h_tr / 1e3, 2), "merge_us": round(h_en / 1e3, 2), "finalize_us": round(h_pk / 1e3, 2),
                          "sum_kernels_us": round((h_tr + h_en + h_pk) / 1e3, 2), "measured": f"single-stream pass of {P - SKIP} launches right behind the timed region"}
             time.sleep(args.roofline_idle_ms / 1e3)
         ns_tr, ns_en, ns_pk, ns_tot = single_stream_pass(B)
@@ -485,7 +490,7 @@ def main():
                 traffic = None
         one = None
         if single_ns:
-            one = {"transform_us": round(single_ns[0] / 1e3, 2), "stitch_us": round(single_ns[2] / 1e3, 2),
+            one = {"transform_us": round(single_ns[0] / 1e3, 2), "merge_us": round(single_ns[1] / 1e3, 2), "finalize_us": round(single_ns[2] / 1e3, 2),
                    "sum_kernels_us": round(sum(single_ns[:3]) / 1e3, 2), "achieved": round(algo_bytes / sum(single_ns[:3]), 1),
                    "frac": round(algo_bytes / sum(single_ns[:3]) / HBM_PEAK_GBS, 4),
                    "measured": f"single-stream pass of {P - SKIP} single-image launches (the literal BASELINE configs[2] launch shape) behind the batched one"}
@@ -517,14 +522,14 @@ def main():
                        "streams_per_rank": nstreams,
                        "parallelism": f"dp{world} (independent images per rank"
                                       + (", async RCCL gather of bitstreams to rank 0)" if dist is not None else ")")},
-            "roofline": {"bound": "hbm", "kernel": "k_tile_encode + k_stitch (sum of durations, SURVEY.md 8d)",
+            "roofline": {"bound": "hbm", "kernel": ("k_tile_encode + k_segment_merge + k_finalize" if ns_en else "k_tile_encode + k_stitch (its duration under finalize_us)") + " (sum of durations, SURVEY.md 8d)",
                          "achieved": round(launch_bytes / ns_sum, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(launch_bytes / ns_sum / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "algorithmic_bytes": launch_bytes, "images_per_launch": B,
                          "hbm_read_frac": round(read_bytes * B / ns_sum / HBM_PEAK_GBS, 4),
                          "dominant_kernel": "k_tile_encode", "dominant_frac": round(launch_bytes / ns_tr / HBM_PEAK_GBS, 4),
                          "per_image_us": round(ns_sum / B / 1e3, 2),
-                         "kernel_us": round(ns_tr / 1e3, 2), "stitch_us": round(ns_pk / 1e3, 2),
+                         "kernel_us": round(ns_tr / 1e3, 2), "merge_us": round(ns_en / 1e3, 2), "finalize_us": round(ns_pk / 1e3, 2),
                          "sum_kernels_us": round(ns_sum / 1e3, 2), "first_to_last_event_us": round(ns_tot / 1e3, 2),
                          "throughput_frac": round(algo_bytes * ips / (elapsed / K * 1e9) / HBM_PEAK_GBS, 4),
                          "measured": roof_note,

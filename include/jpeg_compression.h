@@ -131,6 +131,17 @@ int32_t jpegamd_encode_batch_async(JpegAmdEncoder *enc, const JpegAmdImage *imgs
                                    uint64_t out_capacity, uint64_t *const *out_sizes_dev, int32_t with_container,
                                    void *stream);
 
+/* Which kernels follow k_tile_encode for whole pictures (no reference counterpart: a tuning knob, results are byte-identical).
+ *   PAIR    k_segment_merge + k_finalize: the tiles' bit strings joined per segment, then stitched behind a kernel boundary;
+ *   STITCH  k_stitch: one pass, the offsets handed from workgroup to workgroup inside the launch (decoupled look-back);
+ *   AUTO    (default) PAIR, and STITCH for pictures of 16 384 segments and more (16384^2 and up), where k_finalize's scan over
+ *           every predecessor of every workgroup would grow quadratically.
+ * Takes effect with the next encode on the context. */
+#define JPEGAMD_PIPELINE_AUTO   0
+#define JPEGAMD_PIPELINE_PAIR   1
+#define JPEGAMD_PIPELINE_STITCH 2
+int32_t jpegamd_encoder_set_pipeline(JpegAmdEncoder *enc, int32_t pipeline);
+
 /* Block until the last enqueued encode on this context finished; optionally fetch stats
  * (stats may be NULL).  Returns JPEGAMD_ERR_HUFF_CAPACITY if the output did not fit. */
 int32_t jpegamd_encoder_finish(JpegAmdEncoder *enc, JpegAmdStats *stats);

@@ -1,7 +1,7 @@
 // jpegamd_api.cpp -- C-ABI host layer over the HIP kernels (include/jpeg_compression.h).
 //
-// Level 1 (jpegamd_*): device-resident, stream-ordered encode: k_tile_encode -> k_stitch (whole images); the block-row shards of
-//          one image over several GPUs keep k_segment_merge / k_finalize around the exchange.
+// Level 1 (jpegamd_*): device-resident, stream-ordered encode: k_tile_encode -> k_segment_merge -> k_finalize, or -- very large
+//          pictures, where k_finalize's scan over every predecessor would grow quadratically -- k_tile_encode -> k_stitch.
 // Level 2 (JpegCompression_Init / convertToJpeg): the reference's accelerator boundary
 //          (dsp_port/jpeg_compression/src/jpeg_compression.c:6-33,35-216).
 // There is no CPU fallback: without a HIP device every compute entry fails.
@@ -46,6 +46,7 @@ struct JpegAmdEncoder {
     uint32_t *desc = nullptr;           // k_stitch's hand-off granules: max_wgs x 16 bytes, then max_wgs x 8 counts in full
     int max_wgs = 0;
     uint32_t epoch = 0;                 // 1 .. 16383: tag of the last k_stitch launch's granules
+    int pipeline = JPEGAMD_PIPELINE_AUTO;
     int poison_tile = -1;               // jpegamd_debug_poison_tile_record: the next encode overwrites this tile's record word 0 ...
     uint32_t poison_value = 0;          // ... with this value, between k_tile_encode and k_segment_merge
     unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
@@ -215,6 +216,12 @@ extern "C" int32_t jpegamd_encoder_destroy(JpegAmdEncoder *e) {
     return JPEGAMD_OK;
 }
 
+extern "C" int32_t jpegamd_encoder_set_pipeline(JpegAmdEncoder *e, int32_t pipeline) {
+    if (!e || pipeline < JPEGAMD_PIPELINE_AUTO || pipeline > JPEGAMD_PIPELINE_STITCH) return JPEGAMD_ERR_ARG;
+    e->pipeline = pipeline;
+    return JPEGAMD_OK;
+}
+
 extern "C" int32_t jpegamd_encoder_set_profiling(JpegAmdEncoder *e, int32_t slots) {
     if (!e || slots < 0 || slots > 65536) return JPEGAMD_ERR_ARG;
     if (e->pending) HIP_TRY(hipStreamSynchronize(e->last_stream));
@@ -339,6 +346,31 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     ea.seg = e->seg;
     ea.status = &e->stats_dev->status;
     return launch_segment_merge(ea, stream, ev ? (void *const *)(ev + 2) : nullptr);
+}
+
+static int run_finalize_batch(JpegAmdEncoder *e, const ImageDesc &im, void *const *outs_dev, uint64_t out_capacity,
+                              uint64_t *const *out_sizes_dev, int32_t with_container, hipStream_t stream, hipEvent_t *ev = nullptr) {
+    FinalizeArgs fa;
+    std::memset(&fa, 0, sizeof(fa));
+    fa.seg = e->seg;
+    fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
+    fa.batch = im.batch;
+    fa.use_groups = (im.num_segs % kSegGroup == 0) ? 1 : 0;      // every image then starts on a group boundary
+    for (int i = 0; i < im.batch; ++i) { fa.out[i] = (uint8_t *)outs_dev[i]; fa.out_size[i] = out_sizes_dev[i]; }
+    fa.out_capacity = out_capacity; fa.stats = e->stats_dev;
+    fa.prefix = e->prefix; fa.prefix_len = with_container ? JPEGAMD_JFIF_PREFIX_BYTES : 0;
+    fa.write_eoi = with_container ? 1 : 0;
+    return launch_finalize(fa, stream, (void *const *)ev);
+}
+
+// Which pipeline codes a launch of whole pictures (jpegamd_encoder_set_pipeline): the pair k_segment_merge + k_finalize -- faster
+// up to 8192^2-class pictures and on dense content (profiles/r04_notes_experiments.txt) -- or the single-pass k_stitch, whose
+// look-back reads at most 256 predecessors per round where k_finalize's scan reads every predecessor of every workgroup.
+constexpr int kStitchAutoSegs = 16384;      // 8-tile segments of ONE picture from which AUTO takes k_stitch (a 16384^2 picture)
+static bool use_stitch(const JpegAmdEncoder *e, int w, int h) {
+    if (e->pipeline == JPEGAMD_PIPELINE_PAIR) return false;
+    if (e->pipeline == JPEGAMD_PIPELINE_STITCH) return true;
+    return segs_for(w, h, nullptr, nullptr, nullptr) >= kStitchAutoSegs;
 }
 
 // k_stitch over the tiles k_tile_encode left: whole images, one or a batch.
@@ -479,7 +511,8 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
                                         void *stream_) {
     if (!e || !out_dev || !out_size_dev) return JPEGAMD_ERR_ARG;
     ImageDesc im;
-    int32_t rc = describe(e, img, &im, kSegTilesBatch);                 // whole images: k_stitch works on segments of 16 tiles
+    const bool stitch = use_stitch(e, img ? img->width : 0, img ? img->height : 0);
+    int32_t rc = describe(e, img, &im, stitch ? kSegTilesBatch : kSegTiles);   // (k_stitch works on segments of 16 tiles)
     if (rc) return rc;
     rc = prepare_constants(e, img, with_container != 0);
     if (rc) return rc;
@@ -492,10 +525,17 @@ extern "C" int32_t jpegamd_encode_async(JpegAmdEncoder *e, const JpegAmdImage *i
         ev = e->ring[(size_t)e->last_slot].ev;
         ++e->calls;
     }
-    if (launch_transform(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
-    void *const outs[1] = {out_dev};
-    uint64_t *const sizes[1] = {out_size_dev};
-    if (run_stitch(e, im, outs, out_capacity, sizes, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    if (timed) e->ring[(size_t)e->last_slot].merged = !stitch;
+    if (stitch) {
+        if (launch_transform(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+        void *const outs[1] = {out_dev};
+        uint64_t *const sizes[1] = {out_size_dev};
+        if (run_stitch(e, im, outs, out_capacity, sizes, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    } else {
+        if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+        if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream, ev ? ev + 4 : nullptr,
+                         im.num_segs % kSegGroup == 0)) return JPEGAMD_ERR_HIP;
+    }
     e->last_segs = im.num_segs;
     e->last_stream = stream;
     e->pending = true;
@@ -510,9 +550,15 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
                                               void *stream_) {
     if (!e || !imgs || !outs_dev || !out_sizes_dev || count < 1 || count > kMaxBatch) return JPEGAMD_ERR_ARG;
     ImageDesc im;
-    const int seg_tiles = kSegTilesBatch;                                // whole images: k_stitch works on segments of 16 tiles
+    const bool stitch = use_stitch(e, imgs[0].width, imgs[0].height);
+    int seg_tiles = (stitch || count >= 4) ? kSegTilesBatch : kSegTiles;  // many pictures: longer segments (jpegamd_internal.h); k_stitch: always
     int32_t rc = describe(e, &imgs[0], &im, seg_tiles);
     if (rc) return rc;
+    if (!stitch && seg_tiles != kSegTiles && (size_t)count * im.num_segs * seg_cap_words(seg_tiles) > e->words_cap) {   // (a geometry other than the context's own)
+        seg_tiles = kSegTiles;
+        rc = describe(e, &imgs[0], &im, seg_tiles);
+        if (rc) return rc;
+    }
     for (int i = 0; i < count; ++i) {
         const JpegAmdImage &g = imgs[i];
         if (!outs_dev[i] || !out_sizes_dev[i] || !g.pixels) return JPEGAMD_ERR_ARG;
@@ -522,7 +568,8 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
         im.batch_pixels[i] = (const uint8_t *)g.pixels;
         if ((((uintptr_t)g.pixels) & 3u) != 0) im.fast_ok = 0;
     }
-    if ((int64_t)count * im.num_tiles > e->max_tiles || (int64_t)count * im.num_segs > e->max_segs) return JPEGAMD_ERR_TOO_LARGE;
+    if ((int64_t)count * im.num_tiles > e->max_tiles || (int64_t)count * im.num_segs > e->max_segs ||
+        (!stitch && (size_t)count * im.num_segs * seg_cap_words(seg_tiles) > e->words_cap)) return JPEGAMD_ERR_TOO_LARGE;
     im.batch = count;
     im.tile_end = count * im.num_tiles;
     im.seg_end = count * im.num_segs;
@@ -537,8 +584,14 @@ extern "C" int32_t jpegamd_encode_batch_async(JpegAmdEncoder *e, const JpegAmdIm
         ev = e->ring[(size_t)e->last_slot].ev;
         ++e->calls;
     }
-    if (launch_transform(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
-    if (run_stitch(e, im, outs_dev, out_capacity, out_sizes_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    if (timed) e->ring[(size_t)e->last_slot].merged = !stitch;
+    if (stitch) {
+        if (launch_transform(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+        if (run_stitch(e, im, outs_dev, out_capacity, out_sizes_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    } else {
+        if (launch_transform_and_entropy(e, im, false, nullptr, nullptr, nullptr, stream, ev)) return JPEGAMD_ERR_HIP;
+        if (run_finalize_batch(e, im, outs_dev, out_capacity, out_sizes_dev, with_container, stream, ev ? ev + 4 : nullptr)) return JPEGAMD_ERR_HIP;
+    }
     e->last_segs = count * im.num_segs;
     e->last_stream = stream;
     e->pending = true;

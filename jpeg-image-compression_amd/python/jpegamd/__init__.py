@@ -69,6 +69,7 @@ def _load() -> C.CDLL:
         "jpegamd_encode_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
         "jpegamd_encode_batch_async": (i32, [vp, C.POINTER(Image), i32, C.POINTER(C.c_void_p), u64, C.POINTER(C.c_void_p), i32, vp]),
         "jpegamd_encoder_finish": (i32, [vp, C.POINTER(Stats)]),
+        "jpegamd_encoder_set_pipeline": (i32, [vp, i32]),
         "jpegamd_encoder_set_profiling": (i32, [vp, i32]),
         "jpegamd_encoder_profile": (i32, [vp, i32, C.POINTER(Stats)]),
         "jpegamd_debug_stages": (i32, [vp, C.POINTER(Image), vp, vp, vp]),
@@ -96,6 +97,8 @@ def _load() -> C.CDLL:
         "jpegamd_finalize_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
+        if name == "jpegamd_encoder_set_pipeline" and os.environ.get("JPEGAMD_LIB") and not hasattr(lib, name):
+            continue                                              # (A/B tooling: a variant build of an older round)
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     return lib
@@ -103,7 +106,7 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async jpegamd_encode_batch_async "
-            "jpegamd_encoder_finish jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
+            "jpegamd_encoder_finish jpegamd_encoder_set_pipeline jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
             "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_table jpegamd_segment_meta_words jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
             "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files "
@@ -118,6 +121,7 @@ def quant_table(quality: int = 50):
     return table
 
 
+PIPELINE_AUTO, PIPELINE_PAIR, PIPELINE_STITCH = 0, 1, 2                    # JPEGAMD_PIPELINE_*
 MAX_BATCH = 32                                               # JPEGAMD_MAX_BATCH
 SEG_META_WORDS = int(lib.jpegamd_segment_meta_words())      # metadata words per segment in the sharded-image exchange
 
@@ -236,6 +240,12 @@ class Encoder:
             self.close()
         except Exception:
             pass
+
+    def set_pipeline(self, pipeline: int):
+        """PIPELINE_AUTO / PIPELINE_PAIR (k_segment_merge + k_finalize) / PIPELINE_STITCH (k_stitch): which kernels follow k_tile_encode."""
+        rc = lib.jpegamd_encoder_set_pipeline(self._h, int(pipeline))
+        if rc:
+            raise JpegAmdError(rc, "jpegamd_encoder_set_pipeline")
 
     def set_profiling(self, slots: int):
         rc = lib.jpegamd_encoder_set_profiling(self._h, int(slots))

@@ -21,7 +21,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _encode_batch(jpegamd, bmps, quality, dev):
+def _encode_batch(jpegamd, bmps, quality, dev, pipeline=None):
     """bmps: BMP files of ONE geometry -> their JFIF files through ONE launch of each kernel (one image: the plain entry)."""
     ups = []
     for b in bmps:
@@ -29,6 +29,8 @@ def _encode_batch(jpegamd, bmps, quality, dev):
         ups.append((img, torch.frombuffer(bytearray(b[off:off + img.row_stride * img.height]), dtype=torch.uint8).to(dev)))
     w, h = ups[0][0].width, ups[0][0].height
     enc = jpegamd.Encoder(w, len(bmps) * ((h + 7) // 8 * 8))
+    if pipeline is not None:
+        enc.set_pipeline(pipeline)
     cap = 4096 + 2 * w * h
     outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in bmps]
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in bmps]
@@ -50,8 +52,9 @@ def test_dimension_limits(jpegamd, oracle, dev, w, h):
     for kind, flags, q in ((0, 0, 0), (1, 1, 0), (0, 2, 90)):
         bmps = [jpegamd.synth_bmp(w, h, 70 + i + kind, kind, flags) for i in range(2)]
         want = [oracle.encode_bmp(b, q if q else 50) for b in bmps]
-        assert _encode_batch(jpegamd, bmps[:1], q, dev)[0] == want[0], (w, h, kind, flags, q, "single")
-        assert _encode_batch(jpegamd, bmps, q, dev) == want, (w, h, kind, flags, q, "batch of two")
+        for pipeline in (jpegamd.PIPELINE_PAIR, jpegamd.PIPELINE_STITCH):
+            assert _encode_batch(jpegamd, bmps[:1], q, dev, pipeline)[0] == want[0], (w, h, kind, flags, q, pipeline, "single")
+            assert _encode_batch(jpegamd, bmps, q, dev, pipeline) == want, (w, h, kind, flags, q, pipeline, "batch of two")
 
 
 def test_sweep_slice_through_the_shared_context(jpegamd, oracle, dev):
@@ -89,6 +92,50 @@ def test_sweep_slice_of_batched_launches(jpegamd, oracle, dev):
         kind, flags = rng.randint(0, 3), rng.randint(0, 3)
         q = rng.choice([50, 50, 10, 90, rng.randint(1, 100)])
         bmps = [jpegamd.synth_bmp(w, h, rng.randint(1, 10 ** 6), kind, flags) for _ in range(nb)]
-        got = _encode_batch(jpegamd, bmps, q if q != 50 else 0, dev)
+        got = _encode_batch(jpegamd, bmps, q if q != 50 else 0, dev, jpegamd.PIPELINE_STITCH if i % 2 else jpegamd.PIPELINE_PAIR)
         for j in range(nb):
             assert got[j] == oracle.encode_bmp(bmps[j], q), (i, w, h, nb, j, kind, flags, q)
+
+
+def test_single_pass_stitch_on_every_kind_of_content(jpegamd, oracle, dev):
+    """k_stitch (JPEGAMD_PIPELINE_STITCH) where AUTO would take the pair: photo-like, noise (segments longer than the kernel's bit
+    window: several parts, counted then written), flat (6-bit segments: bytes straddling several segments), gradients; Q = 10, 50, 90,
+    100 (0xFF counts that saturate the hand-off granule); one to many workgroups; the segment only (no container)."""
+    cases = [(8, 8, 2, 0), (16, 8, 2, 0), (1, 1, 1, 0), (264, 1200, 2, 0), (4104, 8, 1, 0), (2048, 2048, 1, 100), (2048, 1024, 1, 90), (3000, 2000, 0, 50),
+             (3000, 2000, 0, 10), (1920, 1080, 3, 50), (520, 16, 1, 100), (8200, 520, 1, 50), (8200, 520, 0, 95), (6000, 4000, 0, 50)]
+    for (w, h, kind, q) in cases:
+        for flags in (0, 3):
+            bmp = jpegamd.synth_bmp(w, h, 300 + w + kind, kind, flags)
+            got = _encode_batch(jpegamd, [bmp], q if q != 50 else 0, dev, jpegamd.PIPELINE_STITCH)[0]
+            assert got == oracle.encode_bmp(bmp, q if q else 50), (w, h, kind, q, flags)
+    # the segment without container, and an output buffer that is too small: the would-be size and status -8
+    bmp = jpegamd.synth_bmp(1500, 700, 5, 1, 0)
+    want = oracle.encode_bmp(bmp)
+    img, off = jpegamd.parse_bmp(bmp)
+    px = torch.frombuffer(bytearray(bmp[off:off + img.row_stride * img.height]), dtype=torch.uint8).to(dev)
+    enc = jpegamd.Encoder(1500, 700)
+    enc.set_pipeline(jpegamd.PIPELINE_STITCH)
+    d = jpegamd.Encoder.image(px.data_ptr(), 1500, 700, img.row_stride, True, jpegamd.ORDER_BGR, 0)
+    for cap, container in ((len(want), False), (len(want), True), (len(want) // 2, True)):
+        out = torch.zeros(len(want) + 64, dtype=torch.uint8, device=dev)
+        size = torch.zeros(1, dtype=torch.int64, device=dev)
+        enc.encode_async(d, out.data_ptr(), cap, size.data_ptr(), container, torch.cuda.current_stream().cuda_stream)
+        if cap < len(want):
+            with pytest.raises(jpegamd.JpegAmdError) as err:
+                enc.finish()
+            assert err.value.code == -8 and int(size.item()) == len(want)
+            assert bytes(out[cap:].cpu().numpy()) == bytes(len(want) + 64 - cap)          # nothing written beyond the capacity
+        else:
+            enc.finish()
+            n = int(size.item())
+            assert bytes(out[:n].cpu().numpy()) == (want if container else want[328:-2])
+
+
+def test_auto_takes_the_single_pass_for_very_large_pictures(jpegamd, oracle, dev):
+    """16 384 segments and more (2056 x 65535: two segments per block row, 8 192 block rows): JPEGAMD_PIPELINE_AUTO codes the picture
+    with k_stitch -- many look-back rounds -- and the pair gives the same bytes (its scan then reads 2 048 predecessors per workgroup)."""
+    w, h = 2056, 65535
+    bmp = jpegamd.synth_bmp(w, h, 11, 0, 0)
+    want = oracle.encode_bmp(bmp)
+    assert _encode_batch(jpegamd, [bmp], 0, dev) == [want]
+    assert _encode_batch(jpegamd, [bmp], 0, dev, jpegamd.PIPELINE_PAIR) == [want]
