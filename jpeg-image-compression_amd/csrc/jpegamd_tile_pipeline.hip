@@ -418,31 +418,40 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         // kernel ran both terms through one accumulator and had to budget 2 x 16 roundings per MFMA: 2.3 x the reference's
         // own evaluation error, i.e. three times as many exact-order events (quant_consts.cpp).
         f32x16 acc[2][2];                      // [term][chain]
+        // One chain = the four k-steps of one term (t) for one half of the matrix rows (H): four A fragments in one batch of
+        // LDS reads, then four MFMAs back to back behind ONE wait.
+        const auto run_chain = [&](const int t, const int H) {
+            const uint32_t *at = &s_afrag[((t * 2 + H) * 4 * 64 + lane) * 4];
+            f16x8 afr[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {          // the A fragments of one term are fetched kAfrBatch at a time so that
-            const uint32_t *at = &s_afrag[(t * 2 * 4 * 64 + lane) * 4];     // the MFMAs issue back to back behind ONE wait
+            for (int i = 0; i < 4; ++i) afr[i] = *reinterpret_cast<const f16x8 *>(&at[(i * 64) * 4]);
+            __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMAs (hipcc otherwise sinks each read next to its use)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[t][H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0], bfrag[0], zero, 0, 0, 0);     // C = 0 as an inline constant: no accumulator clearing
 #pragma unroll
-            for (int s0 = 0; s0 < 4; s0 += kAfrBatch) {
-                f16x8 afr[2][kAfrBatch];
+            for (int i = 1; i < 4; ++i) acc[t][H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[i], bfrag[i], acc[t][H], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // Is any site of group G alive?  |sum| below the group's zero threshold in every lane => every site quantises to an
+        // unflagged 0.  Tested on the hi chain alone (the threshold has the lo chain's bound taken off).
+        const auto group_alive = [&](const int G) -> bool {
+            float m = fmaxf(fabsf(acc[1][(8 * G) >> 4][(8 * G) & 15]), fabsf(acc[1][(8 * G + 1) >> 4][(8 * G + 1) & 15]));
 #pragma unroll
-                for (int H = 0; H < 2; ++H)
-#pragma unroll
-                    for (int i = 0; i < kAfrBatch; ++i) afr[H][i] = *reinterpret_cast<const f16x8 *>(&at[((H * 4 + s0 + i) * 64) * 4]);
-                __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMAs (hipcc otherwise sinks each read next to its use)
-#pragma unroll
-                for (int i = 0; i < kAfrBatch; ++i)
-#pragma unroll
-                    for (int H = 0; H < 2; ++H) {
-                        if (s0 + i == 0) {                 // C = 0 as an inline constant: no accumulator clearing
-                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            acc[t][H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[0], zero, 0, 0, 0);
-                        } else {
-                            acc[t][H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[H][i], bfrag[s0 + i], acc[t][H], 0, 0, 0);
-                        }
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+            for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(acc[1][(8 * G + j) >> 4][(8 * G + j) & 15]));
+            return __ballot(m >= q_lane[128 + G]) != 0ull;
+        };
+        // The hi chains first, the upper matrix rows (zigzag 32..63: groups 2 and 3) ahead of the lower ones: in photo-like content those
+        // groups are dead in two tiles of three, the test on their hi sums runs beside the lower half's MFMAs, and a dead upper half
+        // never runs its lo chain (4 of the 16 MFMAs; an MFMA costs the SIMD's vector side 10-20 cycles beside three other waves,
+        // profiles/r04_ubench_mfma_overlap.txt).
+        bool gact[4];
+        gact[0] = true;
+        run_chain(1, 1);
+        run_chain(1, 0);
+        gact[2] = group_alive(2);
+        gact[3] = group_alive(3);
+        run_chain(0, 0);
+        if (kTaps || gact[2] || gact[3]) run_chain(0, 1);
 
         // (the luma stash behind the MFMAs' operand reads instead of in front of them keeps the 16 operand registers alive into
         //  the quantiser: 15 spilled registers, 8 % slower)
@@ -459,17 +468,9 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 #define JPEGAMD_ACC(site) (acc[1][(site) >> 4][(site) & 15] + acc[0][(site) >> 4][(site) & 15])     /* hi chain + lo chain */
         int n[32];
         uint32_t flagbits = 0;                                      // bit s: site s of this lane is within delta of a rounding tie
-        bool gact[4];
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
-            gact[G] = true;
-            if (G > 0) {                                            // |sum| below the group's zero threshold in every lane?  Tested on the hi chain
-                                                                    // alone (the threshold has the lo chain's bound taken off): no join adds for a skipped group
-                float m = fmaxf(fabsf(acc[1][(8 * G) >> 4][(8 * G) & 15]), fabsf(acc[1][(8 * G + 1) >> 4][(8 * G + 1) & 15]));
-#pragma unroll
-                for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(acc[1][(8 * G + j) >> 4][(8 * G + j) & 15]));
-                gact[G] = __ballot(m >= q_lane[128 + G]) != 0ull;
-            }
+            if (G == 1) gact[1] = group_alive(1);
             if (gact[G]) {
                 float a8[8];                                        // the group's LUT sums (times kMfmaScale)
 #pragma unroll

@@ -323,11 +323,12 @@ def test_reference_sample_images(jpegamd, dev):
 @pytest.mark.gpu
 def test_profiling_ring_reports_the_kernels_own_durations(jpegamd, dev):
     """jpegamd_encoder_set_profiling: every kernel carries its own begin / end events, so the durations are positive, their sum is
-    below the first-begin-to-last-end span (launch gaps), and a 4x larger image takes longer.  Whole images run two kernels
-    (k_tile_encode, k_stitch): the merge figure of the block-row path stays 0."""
+    below the first-begin-to-last-end span (launch gaps), and a 4x larger image takes longer.  With the single-pass pipeline
+    (k_tile_encode, k_stitch) the merge figure stays 0 and k_stitch's duration is reported as ns_pack."""
     res = {}
-    for (w, h) in ((1024, 1024), (2048, 2048)):
+    for (w, h, pipeline) in ((1024, 1024, jpegamd.PIPELINE_PAIR), (2048, 2048, jpegamd.PIPELINE_PAIR), (2048, 2048, jpegamd.PIPELINE_STITCH)):
         enc = jpegamd.Encoder(w, h)
+        enc.set_pipeline(pipeline)
         bmp = jpegamd.synth_bmp(w, h, 3, 0, 0)
         img, px = upload_pixels(bmp, jpegamd, dev)
         cap = 4096 + w * h
@@ -340,11 +341,11 @@ def test_profiling_ring_reports_the_kernels_own_durations(jpegamd, dev):
         enc.finish()
         prof = [enc.profile(s) for s in range(2, 8)]
         for p in prof:
-            assert p.ns_transform > 0 and p.ns_entropy == 0 and p.ns_pack > 0
+            assert p.ns_transform > 0 and p.ns_pack > 0 and (p.ns_entropy > 0) == (pipeline == jpegamd.PIPELINE_PAIR)
             assert p.ns_transform + p.ns_entropy + p.ns_pack <= p.ns_total
             assert p.ns_total < 5_000_000
-        res[w] = sum(p.ns_transform for p in prof) / len(prof)
-    assert res[2048] > res[1024]
+        res[(w, pipeline)] = sum(p.ns_transform for p in prof) / len(prof)
+    assert res[(2048, jpegamd.PIPELINE_PAIR)] > res[(1024, jpegamd.PIPELINE_PAIR)]
 
 
 @pytest.mark.gpu
