@@ -23,8 +23,8 @@ JFIF file bytes in HBM.  A "step" is one pass of the hot path (k_tile_encode -> 
 k_tile_encode -> k_stitch, the single-pass kernel the library itself takes for 16384^2-class pictures) over the step's images, on one HIP stream by default (`--streams`: k_tile_encode is a persistent kernel that fills the GPU; launches on
 several streams queue behind each other's workgroups and were measured slower); every step is a complete encode.  With N > 1 every rank
 encodes its own images (weak scaling, no data-path collective inside the encode) and the finished bitstreams are
-collected at rank 0 with one asynchronous RCCL gather per `--gather-every` images
-(jpegamd.sharding.BatchedStreamGather), overlapped with the following steps.
+collected at rank 0 by a gather-v over RCCL -- per `--gather-every` images one exchange of exact-size transfers
+(jpegamd.sharding.ExactStreamGather: size tables one buffer ahead, one grouped send per rank), overlapped with the following steps.
 
 Extra objects on the JSON line:
   "roofline"      HBM roofline of the encode as SURVEY.md 8d defines it: algorithmic bytes of ONE launch (BMP rows read + JFIF
@@ -241,13 +241,14 @@ def main():
         imgs = [jpegamd.Encoder.image(t.data_ptr(), w, h, stride, True, jpegamd.ORDER_BGR, args.quality) for t in inputs]
         tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
 
-        # N > 1: the finished bitstreams are collected at rank 0, `gather_every` images per collective (few, large
-        # messages: each peer's records cross its own xGMI link to the root in one piece).  The record size is fixed
-        # before the timed region from the sizes the inputs actually produce (+5 %), agreed over all ranks.
+        # N > 1: the finished bitstreams are collected at rank 0, `gather_every` images per exchange, every stream at its exact size
+        # (each peer's bytes cross its own xGMI link to the root).  The encoder writes into staging records whose size is fixed
+        # before the timed region from the sizes the inputs actually produce (+5 %), agreed over all ranks; a stream that outgrows
+        # its record is encoded again by its owner at the exact size (ExactStreamGather).
         gather = None
         G = max(1, args.gather_every)
         if dist is not None:
-            from jpegamd.sharding import BatchedStreamGather
+            from jpegamd.sharding import ExactStreamGather
             biggest = 0
             for im in imgs:
                 encs[0].encode_async(im, outs[0].data_ptr(), cap, sizes[0].data_ptr(), True, tstreams[0].cuda_stream)
@@ -255,9 +256,10 @@ def main():
             t = torch.tensor([biggest], dtype=torch.int64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             slot_bytes = ((int(t.item()) * 21 // 20 + 4096 + 255) // 256) * 256 + 8
-            gather = BatchedStreamGather(slot_bytes, G, torch.device("cuda", local_rank), dst=0, depth=2)
+            gather = ExactStreamGather(slot_bytes, G, torch.device("cuda", local_rank), dst=0, depth=3,
+                                       reencode=lambda n, payload, size: reencode(n, payload, size))
             rec_ptrs = {}
-            for st_i in range(2 * G):
+            for st_i in range(3 * G):
                 pl, sz = gather.record(st_i)
                 rec_ptrs[st_i] = (pl.data_ptr(), pl.numel(), sz.data_ptr(), sz)
         last_image = [-1]
@@ -273,7 +275,7 @@ def main():
                     for n in ns:
                         if n % G < nstreams * B:                      # a stream's first write into this buffer: behind the
                             gather.reserve(n)                         # collective that last read it
-                    optrs = [rec_ptrs[n % (2 * G)][:3] for n in ns]
+                    optrs = [rec_ptrs[n % (3 * G)][:3] for n in ns]
                 if B == 1:
                     encs[si].encode_async(imgs[ns[0] % nimg], optrs[0][0], optrs[0][1], optrs[0][2], True, tstreams[si].cuda_stream)
                 else:
@@ -299,13 +301,8 @@ def main():
                 if last_image[0] % G != G - 1:
                     with torch.cuda.stream(tstreams[0]):
                         commit(last_image[0], True)
-                gather.wait_all()
-                torch.cuda.synchronize()
-                # a stream that outgrew its slot (sized from a sample + 5 %) does not fail the buffer: exact-size second gather
-                oversized[0] += gather.settle(last_image[0], reencode)
+                gather.drain()
             torch.cuda.synchronize()
-
-        oversized = [0]
 
         def reencode(n, payload, size):
             encs[0].encode_async(imgs[n % nimg], payload.data_ptr(), payload.numel(), size.data_ptr(), True, tstreams[0].cuda_stream)
@@ -319,7 +316,7 @@ def main():
                 except jpegamd.JpegAmdError as err:
                     if err.code == -1:                                # nothing pending on this context
                         continue
-                    if gather is not None and err.code == -8:         # a record outgrew its slot: drain()'s settle() collects it
+                    if gather is not None and err.code == -8:         # a stream outgrew its record: its owner encodes it again at the exact size (counted below)
                         continue
                     raise RuntimeError(f"bench.py: an encode in the {where} did not fit its output buffer ({err})")
 
@@ -342,6 +339,7 @@ def main():
 
         n_timed = K * ips
         n_launches = n_timed // B
+        own0 = gather.bytes_own if gather is not None else 0
         for e in encs:
             e.set_profiling(0)                                        # the timed region's launches carry no events (plain hipLaunchKernelGGL)
         if dist is not None:
@@ -367,7 +365,7 @@ def main():
             try:
                 return e.finish()                                     # raises if ANY timed encode overflowed on that context
             except jpegamd.JpegAmdError as err:
-                if gather is not None and err.code in (-1, -8):       # (settle() has collected the oversized records already)
+                if gather is not None and err.code in (-1, -8):       # (oversized streams went out re-encoded: gather.reencoded)
                     return None
                 raise
         st = finish_timed(encs[last_ctx])
@@ -375,7 +373,7 @@ def main():
             if si != last_ctx and n_launches > si:
                 finish_timed(e)
         if gather is not None:                                        # every record of the last buffers carries a plausible size
-            for k in range(min(2 * G, n_timed)):
+            for k in range(min(3 * G, n_timed)):
                 n_bytes = int(rec_ptrs[k][3].item())
                 if n_bytes <= 0:
                     raise RuntimeError(f"bench.py: gather record {k} holds {n_bytes} bytes (capacity {rec_ptrs[k][1]})")
@@ -541,8 +539,11 @@ def main():
             "parity": parity,
         }
         if gather is not None:
-            line["gather"] = {"images_per_collective": G, "record_bytes": slot_bytes, "collectives": gather.collectives,
-                              "records_beyond_their_slot": oversized[0]}
+            line["gather"] = {"images_per_exchange": G, "staging_record_bytes": slot_bytes, "exchanges": gather.exchanges,
+                              "streams_encoded_again_at_exact_size": gather.reencoded,
+                              "gather_GBps_per_rank": round((gather.bytes_own - own0) / elapsed / 1e9, 2),
+                              "note": "exact stream bytes a rank hands to the root per second of the timed region (rank 0's own stay where they are); "
+                                      "at N ranks the root takes in (N - 1) x this, each peer over its own xGMI link (~64 GB/s per direction)"}
         return line, parity_ok, first_bmp
 
     workload = args.workload if args.workload != "auto" else "image8192"

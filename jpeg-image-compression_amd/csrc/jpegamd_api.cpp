@@ -49,7 +49,8 @@ struct JpegAmdEncoder {
     int pipeline = JPEGAMD_PIPELINE_AUTO;
     int poison_tile = -1;               // jpegamd_debug_poison_tile_record: the next encode overwrites this tile's record word 0 ...
     uint32_t poison_value = 0;          // ... with this value, between k_tile_encode and k_segment_merge
-    unsigned long long *stamps_dev = nullptr;   // diagnostic builds (JPEGAMD_STAMPS): per-wave phase cycle sums
+    unsigned long long *stamps_dev = nullptr;   // per-wave phase cycle sums of the stamped kernel (allocated by the first convertToJpeg, or with JPEGAMD_STAMPS=1)
+    bool stamp_next = false;                    // the next k_tile_encode launch is the stamped variant (convertToJpeg)
     // cached constants
     int cur_quality = -1;
     uint8_t qtable[64];
@@ -320,7 +321,10 @@ static int launch_transform(JpegAmdEncoder *e, const ImageDesc &im, bool taps, i
     // i % 2 and zeroes the other one for launch i + 1.
     to.tile_ctr = e->tile_ctr + (e->ctr_set ? 64 * 32 : 0);
     to.tile_ctr_next = e->tile_ctr + (e->ctr_set ? 0 : 64 * 32);
-    if (int err = launch_tile_transform(im, to, taps, stream, (ev && !taps) ? (void *const *)ev : nullptr)) return err;
+    const bool stamped = e->stamp_next && e->stamps_dev && !taps;
+    e->stamp_next = false;
+    if (int err = stamped ? launch_tile_transform_stamped(im, to, taps, stream, ev ? (void *const *)ev : nullptr)
+                          : launch_tile_transform(im, to, taps, stream, (ev && !taps) ? (void *const *)ev : nullptr)) return err;
     if (im.tile_end > im.tile_begin) e->ctr_set ^= 1;      // (an empty range launches nothing)
     if (e->poison_tile >= 0) {                             // fault injection for the tests: a corrupt record must end in a status code
         if (e->poison_tile < e->max_tiles &&
@@ -768,6 +772,14 @@ extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
         int32_t prc = jpegamd_encoder_set_profiling(e, 1);     // the DTO always reports stage times
         if (prc) return prc;
     }
+    // the six stage counters (jpeg_compression.c:188-210) come from the STAMPED variant of the fused kernel: the same code with its
+    // phases bracketed by cycle-counter reads (~10 % slower; the asynchronous entry points never run it)
+    const size_t stamp_words = (size_t)(e->max_segs > 4096 ? e->max_segs : 4096) * 16;
+    if (!e->stamps_dev) {
+        HIP_TRY(hipMalloc((void **)&e->stamps_dev, stamp_words * sizeof(unsigned long long)));
+    }
+    HIP_TRY(hipMemsetAsync(e->stamps_dev, 0, stamp_words * sizeof(unsigned long long), nullptr));
+    e->stamp_next = true;
     int32_t rc = jpegamd_encode_async(e, &img, (void *)(uintptr_t)dto->huff_phy_ptr, dto->huff_size, size_dev, 0, nullptr);
     JpegAmdStats st;
     if (rc == JPEGAMD_OK) rc = jpegamd_encoder_finish(e, &st);
@@ -775,11 +787,10 @@ extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
 
     dto->huff_size = (uint32_t)st.jfif_bytes;
     dto->rle_count = (uint32_t)last_symbol_count(e);
-    // Stage counters (jpeg_compression.c:188-210 fills six), in nanoseconds.  The six stages are phases of ONE kernel here, so
-    // a plain build reports k_tile_encode's duration under cycles_dct, k_segment_merge under cycles_rle, k_finalize under
-    // cycles_huffman, and 0 for the rest.  A diagnostic build (-DJPEGAMD_STAMPS, JPEGAMD_STAMPS=1 in the environment) has
-    // in-kernel phase stamps: k_tile_encode's duration is then split by the phases' shares of the waves' time (zigzag is an
-    // addressing mode of the matrix operand: it has no phase and stays 0).
+    // Stage counters (jpeg_compression.c:188-210 fills six), in nanoseconds.  Colour conversion, DCT, quantisation, run/size symbols
+    // and Huffman coding are phases of ONE kernel here; this call ran its STAMPED variant (above), whose in-kernel cycle-counter
+    // reads split the kernel's duration by the phases' shares of the waves' time.  Zigzag is the row order of the matrix operand
+    // (no instruction, no phase): its counter stays 0.  cycles_rle / cycles_huffman also carry the stitching kernels.
     dto->cycles_color_conversion = 0;
     dto->cycles_dct = st.ns_transform;
     dto->cycles_quantization = 0;
@@ -797,7 +808,7 @@ extern "C" int32_t convertToJpeg(JPEG_COMPRESSION_DTO *dto) {
                 for (int i = 0; i < 11; ++i) ph[i] += (double)stamps[w * 16 + i];
             double all = 0;
             for (double v : ph) all += v;
-            if (all > 0) {                                            // (all zero: not a stamps build)
+            if (all > 0) {
                 const double k = (double)st.ns_transform / all;
                 // phases: 0 loop, 1 wait rows + luma, 2 luma -> LDS, 3 MFMA, 4 quantise, 5 exact order, 6 counts, 7 ticket / row
                 // requests, 8 appends, 9 coding, 10 record / copy-out; the loop's own overhead (0, 7) goes with the colour stage

@@ -136,7 +136,7 @@ struct TransformOutM {
     const uint32_t *code_tab;   // [kCodeWords] device copy of the code table
     uint32_t *tile_ctr;         // [64 groups][32 words]: word 0 = ticket counter of the group's tile hand-out; zero at launch
     uint32_t *tile_ctr_next;    // the set the NEXT launch on this context uses: zeroed by this launch
-    unsigned long long *stamps; // per-wave phase cycle sums (diagnostic builds with -DJPEGAMD_STAMPS only)
+    unsigned long long *stamps; // per-wave phase cycle sums (launch_tile_transform_stamped only)
     int8_t *tap_y;              // stage taps (debug variant only)
     int16_t *tap_zz;
     uint64_t *tap_mask;
@@ -144,6 +144,8 @@ struct TransformOutM {
 // `ev` (optional): two hipEvent_t that receive the kernel's OWN begin / end timestamps (hipExtLaunchKernelGGL), i.e. what a
 // kernel trace reports as its duration -- an event recorded in front of a launch also sees the dispatch latency.
 int launch_tile_transform(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream, void *const *ev = nullptr);
+// the same kernel with its phases stamped (out.stamps must point at 16 words per wave): jpegamd_tile_pipeline.hip, -DJPEGAMD_STAMPED_TU
+int launch_tile_transform_stamped(const ImageDesc &im, const TransformOutM &out, bool taps, void *stream, void *const *ev = nullptr);
 
 struct MergeArgs {              // k_segment_merge: the tile strings of a segment -> ONE bit string per segment + its numbers
     const uint32_t *tile_head, *tile_over;

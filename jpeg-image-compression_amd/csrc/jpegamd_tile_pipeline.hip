@@ -25,6 +25,18 @@
 #include <hip/hip_ext.h>
 #include "jpegamd_device.h"
 
+// This file is compiled TWICE into the library: plain (the hot path: no stamp instruction executed) and with
+// -DJPEGAMD_STAMPED_TU, where every phase of the tile loop is bracketed by s_memtime reads whose per-wave sums leave in
+// TransformOutM::stamps -- launch_tile_transform_stamped, what convertToJpeg runs to fill the six stage counters of the reference's
+// DTO (dsp_port/jpeg_compression/src/jpeg_compression.c:188-210) from ONE fused kernel.  The stamps cost ~10 % of the kernel.
+#ifdef JPEGAMD_STAMPED_TU
+#ifndef JPEGAMD_STAMPS
+#define JPEGAMD_STAMPS 1
+#endif
+#define k_tile_encode k_tile_encode_stamped
+#define launch_tile_transform launch_tile_transform_stamped
+#endif
+
 namespace jpegamd {
 
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;

@@ -86,36 +86,74 @@ class StreamGather:
         return out
 
 
-class BatchedStreamGather:
-    """Few, large collectives: `slots` consecutive results of a rank travel in ONE gather.
+class ExactStreamGather:
+    """gather-v of finished bitstreams: every stream crosses the link at its EXACT size (rounded up to 8 bytes),
+    `slots` consecutive results of a rank per exchange, and a rank's own results never move.
 
-    Each rank owns `depth` staging buffers of `slots` fixed-size records.  A record is `slot_bytes` long: the
-    bitstream at offset 0 and its byte count (int64) in the last 8 bytes, so the encoder writes both straight into
-    the staging buffer (`record(step)` gives the two tensors to point it at) and one collective moves payloads and
-    sizes together.  `commit(step)` starts the asynchronous gather of a buffer when its last record was produced;
-    `reserve(step)` makes the calling stream wait for the gather that last read the buffer `step` is about to
-    overwrite.  Sized for xGMI: at 8 ranks the root receives 7 x slots x slot_bytes per collective, each peer
-    over its own link, instead of one small padded message per image.
-    """
+    Each rank owns `depth` staging buffers of `slots` records.  A record is `slot_bytes` long -- the bitstream at offset 0, its
+    byte count (int64) in the last 8 bytes -- so the encoder writes both straight into the staging buffer (`record(step)`), with
+    no copy between the encoder's output and the wire.  The exchange of a buffer is split so that the host never waits:
 
-    def __init__(self, slot_bytes: int, slots: int, device, group=None, dst: int = 0, depth: int = 2):
+      commit(step)   the buffer is complete (call it on the stream that produced the records): its size table (`slots` int64) is
+                     all-gathered over the ranks on the device and fetched into pinned host memory behind an event; then
+                     flush() posts the transfers of the buffers committed EARLIER, whose tables have long arrived.
+      flush()        sender: one isend per record, exactly the stream's bytes, all of a buffer in ONE batch (one grouped RCCL
+                     launch); root: the matching irecvs into one dense area per rank, at running offsets.  A stream that outgrew
+                     its slot (the encoder then leaves the would-be size and a cut stream) is encoded again by its owner,
+                     `reencode(step, payload, size)`, into a side buffer of the exact size, and THAT is sent: no second exchange,
+                     nothing for the root to know.
+      reserve(step)  orders the calling stream behind the transfers that last read the buffer `step` is about to overwrite.
+      drain()        flushes and waits for everything (host).
+      result(step)   on dst, after drain(): per rank, the streams of the buffer that held `step`.
+
+    A buffer is in flight from its first record until the transfers posted one commit later are through: depth >= 3.
+    At 8 ranks the root posts 7 x slots receives per exchange, each peer's bytes over its own xGMI link."""
+
+    def __init__(self, slot_bytes: int, slots: int, device, group=None, dst: int = 0, depth: int = 3, reencode=None):
         if slot_bytes % 8 or slot_bytes < 16:
             raise ValueError("slot_bytes must be a multiple of 8 (the size field is an aligned int64)")
+        if depth < 3:
+            raise ValueError("depth >= 3: a buffer's transfers are posted one commit after its own")
         self.group, self.dst, self.slot_bytes, self.slots, self.depth = group, dst, int(slot_bytes), int(slots), int(depth)
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist_on else 1
+        self.rank = dist.get_rank(group) if self.dist_on else 0
         self.is_dst = self.rank == dst
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.reencode = reencode
         n = self.slot_bytes * self.slots
         self._stage = [torch.zeros(n, dtype=torch.uint8, device=device) for _ in range(depth)]
-        self._recv = [[torch.empty(n, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.is_dst else None
-                      for _ in range(depth)]
-        self._work = [None] * depth
-        self._extra = [dict() for _ in range(depth)]        # dst: {(rank, record): bytes} of the records collected by settle()
-        self.collectives = 0
-        self.device = device
+        self._sizes = [torch.zeros(self.slots, dtype=torch.int64, device=device) for _ in range(depth)]
+        self._all_sizes = [[torch.zeros(self.slots, dtype=torch.int64, device=device) for _ in range(self.world)] for _ in range(depth)]
+        self._host = [torch.zeros(self.world, self.slots, dtype=torch.int64) for _ in range(depth)]
+        if self.on_gpu:
+            self._host = [h.pin_memory() for h in self._host]
+        self._event = [None] * depth                         # sizes of the buffer's last commit are in _host behind this event
+        self._base = [None] * depth                          # first step of the buffer's last commit
+        self._pending: List[int] = []                        # committed buffers whose transfers are not posted yet (oldest first)
+        self._works = [[] for _ in range(depth)]             # transfers (and the size all-gather) that still read / write the buffer
+        self._side = [dict() for _ in range(depth)]          # record -> exact-size tensor of a stream that outgrew its slot
+        self._recv = [[None] * self.world for _ in range(depth)]
+        self._table = [None] * depth                         # dst: host copy of the sizes the posted receives were made from
+        self._aux = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.exchanges = 0
+        self.bytes_sent = 0                                  # by this rank, exact
+        self.bytes_own = 0                                   # of this rank's own streams (sent, or -- the root -- kept)
+        self.reencoded = 0
 
     def _where(self, step: int) -> Tuple[int, int]:
         return (step // self.slots) % self.depth, step % self.slots
+
+    def _fetch_table(self, b: int) -> None:
+        """(on the current stream) every rank's sizes of buffer b -> pinned host memory"""
+        if self.world > 1:
+            w = dist.all_gather(self._all_sizes[b], self._sizes[b], group=self.group, async_op=True)
+            w.wait()                                         # (RCCL: the current -- side -- STREAM waits, not the host; gloo in the CPU tests: the host)
+            table = torch.stack(self._all_sizes[b])
+        else:
+            table = self._sizes[b].view(1, self.slots)
+        self._host[b].copy_(table, non_blocking=True)
 
     def record(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """(payload uint8[slot_bytes - 8], size int64[1]) views of the record `step` writes into."""
@@ -124,88 +162,128 @@ class BatchedStreamGather:
         return rec[:self.slot_bytes - 8], rec[self.slot_bytes - 8:].view(torch.int64)
 
     def reserve(self, step: int) -> None:
-        """Order the current stream after the collective that last read the buffer of `step` (no-op if none)."""
+        """Order the current stream behind everything that still reads the buffer of `step` (no-op if nothing does)."""
         b, _ = self._where(step)
-        if self._work[b] is not None:
-            self._work[b].wait()
+        if b in self._pending:                               # (only with too shallow a ring: post them now)
+            self.flush()
+        for w in self._works[b]:
+            w.wait()
+        self._works[b] = []
 
-    def commit(self, step: int, force: bool = False):
-        """After record `step` was produced on the current stream: start the gather if the buffer is complete."""
+    def commit(self, step: int, force: bool = False) -> bool:
+        """After record `step` was produced on the current stream: if the buffer is complete (or `force`), send its size table
+        on its way and post the transfers of the buffers committed before.  -> whether the buffer was committed."""
         b, k = self._where(step)
         if k != self.slots - 1 and not force:
-            return None
-        self._work[b] = dist.gather(self._stage[b], self._recv[b], dst=self.dst, group=self.group, async_op=True)
-        self.collectives += 1
-        return self._work[b]
-
-    def wait_all(self) -> None:
-        for w in self._work:
-            if w is not None:
-                w.wait()
-
-    def settle(self, step: int, reencode=None) -> int:
-        """Collective (EVERY rank calls it, once the gather of the buffer holding `step` was waited for): a record whose
-        stream did not fit its slot -- the encoder stores the would-be byte count even then, so its size field exceeds
-        slot_bytes - 8 -- does not fail the buffer: its rank encodes that image again, `reencode(record_step, payload_tensor,
-        size_tensor)`, into a buffer of the exact size, and ONE more gather collects all of them.  `result()` then returns the
-        complete streams.  Returns the number of such records over all ranks; 0 (the usual case) costs one small all-reduce."""
-        b, _ = self._where(step)
-        base = (step // self.slots) * self.slots
+            return False
         cap = self.slot_bytes - 8
-        sizes = self._stage[b].view(self.slots, self.slot_bytes)[:, cap:].contiguous().view(torch.int64).cpu().reshape(-1)
-        mine = [k for k in range(self.slots) if int(sizes[k]) > cap]
-        agree = torch.tensor([len(mine), max([int(sizes[k]) for k in mine], default=0)], dtype=torch.int64, device=self.device)
-        dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=self.group)
-        count, biggest = int(agree[0].item()), int(agree[1].item())
-        self._extra[b] = dict()
-        if count == 0:
-            return 0
-        if reencode is None:
-            raise RuntimeError(f"{count} record(s) did not fit their slot of {cap} bytes and no reencode callback was given")
-        rec_bytes = (biggest + 7) // 8 * 8 + 16                       # payload, its byte count, the record's index in the buffer
-        ext = torch.zeros(count * rec_bytes, dtype=torch.uint8, device=self.device)
-        tail = ext.view(count, rec_bytes)[:, rec_bytes - 16:]
-        for j in range(count):
-            idx = tail[j, 8:].view(torch.int64)
-            idx.fill_(-1)                                             # (unused rows of a rank with fewer offenders)
-        for j, k in enumerate(mine):
-            row = ext[j * rec_bytes:(j + 1) * rec_bytes]
-            reencode(base + k, row[:rec_bytes - 16], row[rec_bytes - 16:rec_bytes - 8].view(torch.int64))
-            row[rec_bytes - 8:].view(torch.int64).fill_(k)
-        recv = [torch.empty_like(ext) for _ in range(self.world)] if self.is_dst else None
-        dist.gather(ext, recv, dst=self.dst, group=self.group)
-        self.collectives += 1
-        if self.is_dst:
-            for r in range(self.world):
-                buf = recv[r].cpu().view(count, rec_bytes)
-                for j in range(count):
-                    n = int(buf[j, rec_bytes - 16:rec_bytes - 8].view(torch.int64).item())
-                    k = int(buf[j, rec_bytes - 8:].view(torch.int64).item())
-                    if k < 0:
-                        continue
-                    if not (0 < n <= rec_bytes - 16):
-                        raise RuntimeError(f"re-encoded record {k} of rank {r} holds {n} bytes (capacity {rec_bytes - 16})")
-                    self._extra[b][(r, k)] = bytes(buf[j, :n].numpy())
-        return sum(1 for _ in mine) if not self.is_dst else len(self._extra[b])
+        self._sizes[b].copy_(self._stage[b].view(self.slots, self.slot_bytes)[:, cap:].contiguous().view(torch.int64).reshape(-1))
+        # The table travels on a side stream: the producing stream never waits for another rank here.
+        if self.on_gpu:
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self._aux):
+                self._aux.wait_event(ready)
+                self._fetch_table(b)
+                self._event[b] = torch.cuda.Event()
+                self._event[b].record()
+        else:
+            self._fetch_table(b)
+        self._base[b] = (step // self.slots) * self.slots
+        self._side[b] = dict()
+        self.flush()                                         # the buffers committed EARLIER: their tables are on the host by now
+        self._pending.append(b)
+        return True
+
+    def flush(self) -> None:
+        """Post the transfers of every committed buffer whose size table has been requested (waits for the table: it is at least
+        one buffer old when commit() calls this)."""
+        while self._pending:
+            b = self._pending.pop(0)
+            if self._event[b] is not None:
+                self._event[b].synchronize()
+            sizes = self._host[b].clone()
+            cap = self.slot_bytes - 8
+            ops = []
+            if True:                                         # every rank, the root too: its own oversized streams
+                mine = sizes[self.rank]
+                for k in range(self.slots):
+                    n = int(mine[k])
+                    self.bytes_own += max(n, 0)
+                    if n > cap:                              # the stream outgrew its slot: once more, at the exact size
+                        if self.reencode is None:
+                            raise RuntimeError(f"record {k} holds {n} bytes, its slot {cap}, and no reencode callback was given")
+                        side = torch.zeros((n + 7) // 8 * 8 + 8, dtype=torch.uint8, device=self.device)
+                        self.reencode(self._base[b] + k, side[:-8], side[-8:].view(torch.int64))
+                        self._side[b][k] = side
+                        self.reencoded += 1
+            if self.world > 1:
+                if not self.is_dst:
+                    for k in range(self.slots):
+                        n = int(sizes[self.rank][k])
+                        if n <= 0:
+                            continue
+                        n8 = (n + 7) // 8 * 8
+                        src = self._side[b][k][:n8] if k in self._side[b] else self._stage[b][k * self.slot_bytes:k * self.slot_bytes + n8]
+                        ops.append(dist.P2POp(dist.isend, src, self.dst, self.group))
+                        self.bytes_sent += n8
+                else:
+                    for r in range(self.world):
+                        if r == self.rank:
+                            continue
+                        total = sum((int(x) + 7) // 8 * 8 for x in sizes[r] if int(x) > 0)
+                        if self._recv[b][r] is None or self._recv[b][r].numel() < total:
+                            self._recv[b][r] = torch.empty(max(total, self.slots * self.slot_bytes), dtype=torch.uint8, device=self.device)
+                        off = 0
+                        for k in range(self.slots):
+                            n = int(sizes[r][k])
+                            if n <= 0:
+                                continue
+                            n8 = (n + 7) // 8 * 8
+                            ops.append(dist.P2POp(dist.irecv, self._recv[b][r][off:off + n8], r, self.group))
+                            off += n8
+                if ops:
+                    self._works[b].extend(dist.batch_isend_irecv(ops))
+                    self.exchanges += 1
+            self._table[b] = sizes
+
+    def drain(self) -> None:
+        """Host: post what is left and wait for every transfer."""
+        self.flush()
+        for b in range(self.depth):
+            for w in self._works[b]:
+                w.wait()
+            self._works[b] = []
+        if self.on_gpu:
+            torch.cuda.synchronize()
 
     def result(self, step: int) -> List[List[bytes]]:
-        """On dst, after wait_all() and a device synchronise: per rank, the streams of the buffer holding `step`."""
+        """On dst, after drain(): per rank, the streams of the buffer that held `step`."""
         if not self.is_dst:
             return []
         b, _ = self._where(step)
+        sizes = self._table[b]
+        if sizes is None:
+            raise RuntimeError("result() before the buffer was committed and drained")
         out = []
         for r in range(self.world):
-            buf = self._recv[b][r].cpu()
             streams = []
-            for k in range(self.slots):
-                rec = buf[k * self.slot_bytes:(k + 1) * self.slot_bytes]
-                n = int(rec[self.slot_bytes - 8:].view(torch.int64).item())
-                if (r, k) in self._extra[b]:                          # it did not fit its slot: collected by settle()
-                    streams.append(self._extra[b][(r, k)])
-                    continue
-                if n < 0 or n > self.slot_bytes - 8:
-                    raise RuntimeError(f"gathered size {n} outside the record ({self.slot_bytes - 8}); call settle() on every rank")
-                streams.append(bytes(rec[:n].numpy()))
+            if r == self.rank:                               # the root's own streams never moved
+                stage = self._stage[b].cpu()
+                for k in range(self.slots):
+                    n = int(sizes[r][k])
+                    src = self._side[b][k].cpu() if k in self._side[b] else stage[k * self.slot_bytes:(k + 1) * self.slot_bytes]
+                    streams.append(bytes(src[:n].numpy()) if n > 0 else b"")
+            else:
+                buf = self._recv[b][r].cpu() if self._recv[b][r] is not None else None
+                off = 0
+                for k in range(self.slots):
+                    n = int(sizes[r][k])
+                    if n <= 0:
+                        streams.append(b"")
+                        continue
+                    streams.append(bytes(buf[off:off + n].numpy()))
+                    off += (n + 7) // 8 * 8
             out.append(streams)
         return out
 

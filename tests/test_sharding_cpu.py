@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: two gloo ranks shard independent images and gather the finished
-bitstreams at rank 0 with the same StreamGather bench.py uses over RCCL.  The encoder itself
+bitstreams at rank 0 with the same gather classes bench.py uses over RCCL.  The encoder itself
 needs a GPU, so the per-rank "encode" here is the oracle (a checker standing in for the device);
 what is under test is the sharding arithmetic and the padded gather."""
 from __future__ import annotations
@@ -84,68 +84,94 @@ def test_two_rank_gloo_gather_of_bitstreams():
     assert ret.get("ok") is True and ret.get("n") == n_images
 
 
-def _batched_worker(rank: int, world: int, port: int, ret):
+def _exact_worker(rank: int, world: int, port: int, ret):
     for p in (str(PKG / "python"), str(ROOT)):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import jpegamd
-    from jpegamd.sharding import BatchedStreamGather
+    from jpegamd.sharding import ExactStreamGather
     from oracle import oracle
-    slots, steps = 3, 9                                   # three full buffers through a depth-2 ring
-    g = BatchedStreamGather(2048, slots, torch.device("cpu"), dst=0, depth=2)
+    slots, steps = 3, 12                                  # four full buffers through a depth-3 ring
+
+    def stream_of(r, s):
+        return oracle.encode_bmp(jpegamd.synth_bmp(16 + s, 8 + 8 * r, 7 * r + s, 0, 0))
+
+    g = ExactStreamGather(2048, slots, torch.device("cpu"), dst=0, depth=3)
     ok = True
+    committed = 0
     for s in range(steps):
         g.reserve(s)
         payload, size = g.record(s)
-        jf = oracle.encode_bmp(jpegamd.synth_bmp(16 + s, 8 + 8 * rank, 7 * rank + s, 0, 0))
+        jf = stream_of(rank, s)
         payload[:len(jf)] = torch.frombuffer(bytearray(jf), dtype=torch.uint8)
         size[0] = len(jf)
-        started = g.commit(s)
-        assert (started is not None) == (s % slots == slots - 1)
-        if started is not None:
-            g.wait_all()
+        did = g.commit(s)
+        assert did == (s % slots == slots - 1)
+        committed += int(did)
+        if did and s >= 2 * slots - 1:                    # the buffer committed one commit ago has been posted by now
+            prev = s - slots
+            g.reserve(prev)                               # (waits for that buffer's transfers; a second wait on a gloo work never returns)
             if rank == 0:
-                res = g.result(s)
+                res = g.result(prev)
                 for r in range(world):
                     for k in range(slots):
-                        step = s - slots + 1 + k
-                        ok &= res[r][k] == oracle.encode_bmp(jpegamd.synth_bmp(16 + step, 8 + 8 * r, 7 * r + step, 0, 0))
+                        ok &= res[r][k] == stream_of(r, prev - slots + 1 + k)
+    g.drain()
     if rank == 0:
+        res = g.result(steps - 1)
+        for r in range(world):
+            for k in range(slots):
+                ok &= res[r][k] == stream_of(r, steps - slots + k)
         ret["ok"] = bool(ok)
-        ret["collectives"] = g.collectives
+        ret["exchanges"] = g.exchanges
+    else:
+        ret["sent"] = g.bytes_sent
+        ret["exact"] = sum((len(stream_of(rank, s)) + 7) // 8 * 8 for s in range(steps))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_batched_gather():
-    """bench.py's N > 1 exchange: several images per collective, sizes carried inside the records."""
+def test_two_rank_gloo_exact_size_gather():
+    """bench.py's N > 1 exchange (gather-v): several images per exchange, every stream at its exact size, the size tables one
+    buffer ahead of the transfers."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_batched_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-    assert ret.get("ok") is True and ret.get("collectives") == 3
+    mp.spawn(_exact_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret.get("ok") is True and ret.get("exchanges") == 4
+    assert ret.get("sent") == ret.get("exact") and ret.get("sent") < 12 * 2048      # what crossed the link is what the streams weigh
 
 
 def _oversize_worker(rank, world, port, ret):
-    """One stream of rank 1 does not fit its slot: settle() has that rank produce it again at the exact size."""
+    """One stream of rank 1 -- and one of the root itself -- does not fit its slot: its owner produces it again at the exact size
+    and THAT is what travels (no second exchange)."""
     for p in (str(PKG / "python"), str(ROOT)):
         sys.path.insert(0, p)
     import jpegamd
-    from jpegamd.sharding import BatchedStreamGather
+    from jpegamd.sharding import ExactStreamGather
     from oracle import oracle
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     slots = 4
+    big = {(1, 2), (0, 1)}
 
     def stream_of(r, s):
-        # record 2 of rank 1 is a 96x64 noise image (a few KB); the others are tiny
-        return oracle.encode_bmp(jpegamd.synth_bmp(96, 64, 5, 1, 0) if (r, s) == (1, 2) else jpegamd.synth_bmp(16 + s, 8, 3 * r + s, 0, 0))
+        # the big ones are 96x64 noise images (a few KB); the others are tiny
+        return oracle.encode_bmp(jpegamd.synth_bmp(96, 64, 5 + r, 1, 0) if (r, s % slots) in big else jpegamd.synth_bmp(16 + s, 8, 3 * r + s, 0, 0))
 
-    slot_bytes = (max(len(stream_of(r, s)) for r in range(world) for s in range(slots) if (r, s) != (1, 2)) + 15) // 8 * 8 + 8
-    assert len(stream_of(1, 2)) > slot_bytes
-    g = BatchedStreamGather(slot_bytes, slots, torch.device("cpu"), dst=0, depth=2)
+    slot_bytes = (max(len(stream_of(r, s)) for r in range(world) for s in range(slots) if (r, s) not in big) + 15) // 8 * 8 + 8
+    assert all(len(stream_of(r, s)) > slot_bytes for (r, s) in big)
+    calls = []
+
+    def reencode(step, payload, size):
+        jf = stream_of(rank, step)
+        payload[:len(jf)] = torch.frombuffer(bytearray(jf), dtype=torch.uint8)
+        size[0] = len(jf)
+        calls.append(step)
+
+    g = ExactStreamGather(slot_bytes, slots, torch.device("cpu"), dst=0, depth=3, reencode=reencode)
     for s in range(slots):
         payload, size = g.record(s)
         jf = stream_of(rank, s)
@@ -153,28 +179,22 @@ def _oversize_worker(rank, world, port, ret):
         payload[:n] = torch.frombuffer(bytearray(jf[:n]), dtype=torch.uint8)
         size[0] = len(jf)
         g.commit(s)
-    g.wait_all()
-
-    def reencode(step, payload, size):
-        jf = stream_of(rank, step)
-        payload[:len(jf)] = torch.frombuffer(bytearray(jf), dtype=torch.uint8)
-        size[0] = len(jf)
-
-    n_over = g.settle(slots - 1, reencode)
+    g.drain()
+    ret[f"calls{rank}"] = list(calls)
     if rank == 0:
         res = g.result(slots - 1)
         ret["ok"] = all(res[r][s] == stream_of(r, s) for r in range(world) for s in range(slots))
-        ret["n_over"] = n_over
-        ret["collectives"] = g.collectives
+        ret["exchanges"] = g.exchanges
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_gloo_gather_with_an_oversized_stream():
-    """A record that does not fit its slot no longer fails the buffer (a real configs[3] stream with one dense image):
-    the offenders travel in a second, exact-size gather."""
+    """A record that does not fit its slot does not fail the buffer (a real configs[3] stream with one dense image): its owner
+    encodes it again into a buffer of the exact size before the transfers are posted."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_oversize_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-    assert ret.get("ok") is True and ret.get("n_over") == 1 and ret.get("collectives") == 2
+    assert ret.get("ok") is True and ret.get("exchanges") == 1
+    assert ret.get("calls0") == [1] and ret.get("calls1") == [2]
