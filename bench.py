@@ -306,7 +306,13 @@ def main():
 
         def reencode(n, payload, size):
             encs[0].encode_async(imgs[n % nimg], payload.data_ptr(), payload.numel(), size.data_ptr(), True, tstreams[0].cuda_stream)
-            encs[0].finish()
+            try:
+                encs[0].finish()
+            except jpegamd.JpegAmdError as err:                       # (the capacity status is sticky: the first encode of this image may have set it)
+                if err.code != -8:
+                    raise
+            if not 0 < int(size.item()) <= payload.numel():
+                raise RuntimeError(f"bench.py: image {n} encoded again into {payload.numel()} bytes reports {int(size.item())}")
 
         def check_capacity(where):
             """The capacity status is sticky on the device: finish() reports an overflow of ANY encode since the last finish."""

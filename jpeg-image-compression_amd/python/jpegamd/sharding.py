@@ -177,7 +177,8 @@ class ExactStreamGather:
         if k != self.slots - 1 and not force:
             return False
         cap = self.slot_bytes - 8
-        self._sizes[b].copy_(self._stage[b].view(self.slots, self.slot_bytes)[:, cap:].contiguous().view(torch.int64).reshape(-1))
+        # (ONE strided copy kernel: the last int64 of every record; a byte-wise .contiguous() of the same column is a copy per record)
+        self._sizes[b].copy_(self._stage[b].view(torch.int64).view(self.slots, self.slot_bytes // 8)[:, -1])
         # The table travels on a side stream: the producing stream never waits for another rank here.
         if self.on_gpu:
             ready = torch.cuda.Event()
