@@ -307,6 +307,21 @@ int32_t jpegamd_finalize_async(JpegAmdEncoder *enc, const JpegAmdImage *img, voi
                                uint64_t out_capacity, uint64_t *out_size_dev, int32_t with_container,
                                void *stream);
 
+/* ---- Independent images sharded over the GPUs of a node: the exchange step as a C entry (no reference counterpart: its
+ * accelerator is one DSP core; the role is that of the host loop in dsp_port/jpeg_client/main.c:397-530) ------------------------
+ * One process per GPU encodes its own images with jpegamd_encode_async / _batch_async, pointing image k's output at a staging
+ * RECORD: `slot_bytes` long, the stream at offset 0 (capacity slot_bytes - 8), its byte count -- out_size_dev -- in the record's
+ * last 8 bytes.  jpegamd_gather_streams then moves the `slots` records of every rank to `root` over RCCL as a gather-v: one
+ * all-gather of the size tables, one host wait, one grouped launch of exact-size sends / receives (rounded up to 8 bytes) on
+ * `stream`; synchronous.  `rccl_comm` is the caller's ncclComm_t (RCCL is dlopen'ed here, the library does not link it).
+ *   sizes_host  HOST, [world][slots], filled on every rank.  A count above slot_bytes - 8 marks a stream the encoder had to
+ *               cut: it does not travel; its owner encodes it again into a buffer of that size and sends it by itself.
+ *   recv        DEVICE, root only: rank r's streams densely from recv + r * recv_stride on, in record order, each rounded up to
+ *               8 bytes (the root's own included).  JPEGAMD_ERR_HUFF_CAPACITY when a rank's total exceeds recv_stride. */
+int32_t jpegamd_gather_streams(void *rccl_comm, int32_t rank, int32_t world, int32_t root, const void *records_dev,
+                               uint64_t slot_bytes, int32_t slots, uint64_t *sizes_host, void *recv_dev, uint64_t recv_stride,
+                               void *stream);
+
 /* File-to-file batch encoding with the host I/O and the PCIe transfers overlapped (no
  * reference counterpart: natural_c/src/main.c:21-24 handles one file, synchronously).
  * Files are processed in order with a few in flight: pinned staging buffers, one HIP stream

@@ -91,13 +91,14 @@ def _load() -> C.CDLL:
         "saveJPEGGrayscale": (C.c_bool, [C.c_char_p, C.POINTER(BMPImage)]),
         "jpegamd_encode_bmp_memory": (i64, [vp, u64, i32, vp, u64]),
         "jpegamd_parse_bmp": (i32, [vp, u64, C.POINTER(Image), C.POINTER(u64)]),
+        "jpegamd_gather_streams": (i32, [vp, i32, i32, i32, vp, u64, i32, vp, vp, u64, vp]),
         "jpegamd_encode_rows_async": (i32, [vp, C.POINTER(Image), i32, i32, vp]),
         "jpegamd_export_segments": (i32, [vp, C.POINTER(Image), i32, i32, vp, u64, vp, vp, vp]),
         "jpegamd_import_segments": (i32, [vp, C.POINTER(Image), i32, i32, vp, vp, vp]),
         "jpegamd_finalize_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
-        if name == "jpegamd_encoder_set_pipeline" and os.environ.get("JPEGAMD_LIB") and not hasattr(lib, name):
+        if name in ("jpegamd_encoder_set_pipeline", "jpegamd_gather_streams") and os.environ.get("JPEGAMD_LIB") and not hasattr(lib, name):
             continue                                              # (A/B tooling: a variant build of an older round)
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
@@ -109,7 +110,7 @@ EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_byt
             "jpegamd_encoder_finish jpegamd_encoder_set_pipeline jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
             "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_table jpegamd_segment_meta_words jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
-            "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files "
+            "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files jpegamd_gather_streams "
             "jpegamd_encode_rows_async jpegamd_export_segments jpegamd_import_segments jpegamd_finalize_async").split()
 
 

@@ -139,3 +139,61 @@ def test_auto_takes_the_single_pass_for_very_large_pictures(jpegamd, oracle, dev
     want = oracle.encode_bmp(bmp)
     assert _encode_batch(jpegamd, [bmp], 0, dev) == [want]
     assert _encode_batch(jpegamd, [bmp], 0, dev, jpegamd.PIPELINE_PAIR) == [want]
+
+
+def test_c_level_gather_of_streams_over_rccl(jpegamd, oracle, dev):
+    """jpegamd_gather_streams (the multi-GPU exchange as a C entry) with a one-rank RCCL communicator made through ctypes: five
+    images encoded straight into staging records, one of them too small for its stream; the size table comes back in full (the
+    cut stream's would-be size included), the streams that fit land densely, 8-byte aligned, in record order."""
+    import ctypes as C
+    try:
+        rccl = C.CDLL("librccl.so")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid, comm = UniqueId(), C.c_void_p()
+    rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        w, h, slots = 640, 360, 5
+        bmps = [jpegamd.synth_bmp(w, h, 60 + k, 1 if k == 3 else 0, 0) for k in range(slots)]       # record 3: noise, several times the others
+        want = [oracle.encode_bmp(b) for b in bmps]
+        slot_bytes = (max(len(x) for k, x in enumerate(want) if k != 3) + 64 + 7) // 8 * 8 + 8
+        assert len(want[3]) > slot_bytes - 8
+        records = torch.zeros(slots * slot_bytes, dtype=torch.uint8, device=dev)
+        enc = jpegamd.Encoder(w, h)
+        keep = []
+        for k, b in enumerate(bmps):
+            img, off = jpegamd.parse_bmp(b)
+            px = torch.frombuffer(bytearray(b[off:off + img.row_stride * img.height]), dtype=torch.uint8).to(dev)
+            keep.append(px)
+            d = jpegamd.Encoder.image(px.data_ptr(), w, h, img.row_stride, True, jpegamd.ORDER_BGR, 0)
+            base = records.data_ptr() + k * slot_bytes
+            enc.encode_async(d, base, slot_bytes - 8, base + slot_bytes - 8, True, torch.cuda.current_stream().cuda_stream)
+        with pytest.raises(jpegamd.JpegAmdError) as err:
+            enc.finish()
+        assert err.value.code == -8                                        # record 3 did not fit
+        sizes = (C.c_uint64 * slots)()
+        stride = slots * slot_bytes
+        recv = torch.zeros(stride, dtype=torch.uint8, device=dev)
+        rc = jpegamd.lib.jpegamd_gather_streams(comm, 0, 1, 0, records.data_ptr(), slot_bytes, slots, C.addressof(sizes), recv.data_ptr(), stride,
+                                                torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        assert list(sizes) == [len(x) for x in want]
+        got, off = recv.cpu().numpy().tobytes(), 0
+        for k in range(slots):
+            if k == 3:
+                continue                                                   # cut by the encoder: its owner sends it by itself, at sizes[3] bytes
+            assert got[off:off + len(want[k])] == want[k], k
+            off += (len(want[k]) + 7) // 8 * 8
+        assert jpegamd.lib.jpegamd_gather_streams(comm, 0, 1, 0, records.data_ptr(), slot_bytes, slots, C.addressof(sizes), recv.data_ptr(), 64,
+                                                  torch.cuda.current_stream().cuda_stream) == -8      # a receive area that is too small
+        assert jpegamd.lib.jpegamd_gather_streams(None, 0, 1, 0, records.data_ptr(), slot_bytes, slots, C.addressof(sizes), recv.data_ptr(), stride, None) == -1
+    finally:
+        rccl.ncclCommDestroy(comm)
