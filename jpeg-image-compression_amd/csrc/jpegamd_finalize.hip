@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_finalize(const FinalizeArgs 
         }
     } else if (base + nown + my_ff > a.out_capacity) {
         overflow = true;
+        running = my_ff;                                            // (the would-be size stays exact: callers size their second attempt from it)
     } else {
         // 0xFF among the owned bytes (one byte in ~300 of photo-like content: nearly every segment of 16 tiles has some).  Sixteen
         // owned bytes per lane and pass, built from the bit string as in the branch above; a wave prefix sum over the lanes' 0xFF

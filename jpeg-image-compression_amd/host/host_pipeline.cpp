@@ -8,11 +8,17 @@
 //                                                         no flip, no channel swap: those are addressing modes of the kernel)
 //     enqueues H2D of the pixel rows, the encode, and the D2H of the 8-byte size
 // and then drains the slot of file i - (kSlots - 1): waits for its size, enqueues the D2H of exactly that many bytes,
-// waits, writes the .jpg.  The reads themselves run on kReaders background threads (a single thread's fread into
-// pinned memory tops out near 5 GB/s, far below PCIe): reader t fills the slots of files t, t + kReaders, ... as
-// soon as the slot's previous upload has left its pinned buffer.
+// waits, writes the .jpg.  The reads themselves run in the background: kReaders staging threads (reader t fills the slots of
+// files t, t + kReaders, ... as soon as the slot's previous upload has left its pinned buffer), each splitting its file over
+// kReadLanes pread() calls on disjoint chunks -- one thread copying out of the page cache into pinned memory tops out near
+// 5 GB/s, far below PCIe.  The slots (pinned + device buffers, stream, encoder context: hundreds of MB of allocations) are
+// kept between calls.
 // Host code only; every byte of the stream is produced by the same device path as jpegamd_encode_async.
 #include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -29,6 +35,8 @@ namespace {
 
 constexpr int kSlots = 4;
 constexpr int kReaders = 2;
+constexpr int kReadLanes = 6;                     // pread() calls in flight per file being staged (12 copying threads in all)
+constexpr size_t kReadChunk = 8u << 20;
 
 struct Slot {
     JpegAmdEncoder *enc = nullptr;
@@ -112,17 +120,36 @@ void stage_file(Slot &s, int index, const char *path, std::atomic<long long> *re
     const double t0 = now_s();
     int32_t rc = JPEGAMD_OK;
     size_t got = 0;
-    FILE *fp = path ? std::fopen(path, "rb") : nullptr;
-    if (!fp) {
+    const int fd = path ? ::open(path, O_RDONLY) : -1;
+    if (fd < 0) {
         rc = JPEGAMD_ERR_BMP;
     } else {
-        std::fseek(fp, 0, SEEK_END);
-        const long len = std::ftell(fp);
-        std::fseek(fp, 0, SEEK_SET);
+        struct stat sb;
+        const long long len = ::fstat(fd, &sb) == 0 ? (long long)sb.st_size : -1;
         if (len <= 0) rc = JPEGAMD_ERR_BMP;
         else if (!s.grow_in((size_t)len)) rc = JPEGAMD_ERR_HIP;
-        else got = std::fread(s.h_in, 1, (size_t)len, fp);
-        std::fclose(fp);
+        else {
+            // chunks of the file, handed out to kReadLanes threads through one counter
+            const size_t nchunks = ((size_t)len + kReadChunk - 1) / kReadChunk;
+            std::atomic<size_t> next{0}, done{0};
+            const auto lane = [&] {
+                for (size_t c = next.fetch_add(1); c < nchunks; c = next.fetch_add(1)) {
+                    size_t off = c * kReadChunk, left = (size_t)len - off < kReadChunk ? (size_t)len - off : kReadChunk;
+                    while (left) {
+                        const ssize_t n = ::pread(fd, s.h_in + off, left, (off_t)off);
+                        if (n <= 0) break;
+                        off += (size_t)n; left -= (size_t)n; done.fetch_add((size_t)n);
+                    }
+                }
+            };
+            std::vector<std::thread> lanes;
+            const int nl = nchunks < (size_t)kReadLanes ? (int)nchunks : kReadLanes;
+            for (int t = 1; t < nl; ++t) lanes.emplace_back(lane);
+            lane();
+            for (std::thread &t : lanes) t.join();
+            got = done.load();
+        }
+        ::close(fd);
     }
     read_ns->fetch_add((long long)((now_s() - t0) * 1e9));
     std::lock_guard<std::mutex> lk(s.mu);
@@ -217,10 +244,19 @@ extern "C" int32_t jpegamd_encode_files(const char *const *in_paths, const char 
     JpegAmdBatchStats bs;
     std::memset(&bs, 0, sizeof(bs));
     const double t_begin = now_s();
-    std::vector<Slot> slots((size_t)(count < kSlots ? (count > 0 ? count : 1) : kSlots));
+    // The slots live as long as the process (one call at a time: the header's threading contract): a second call finds its pinned
+    // and device buffers, streams and encoder contexts in place.
+    static std::mutex pool_mu;
+    static std::vector<Slot> *pool = nullptr;
+    std::lock_guard<std::mutex> pool_lk(pool_mu);
+    if (!pool) pool = new std::vector<Slot>((size_t)kSlots);
+    const size_t nslots = (size_t)(count < kSlots ? (count > 0 ? count : 1) : kSlots);
+    std::vector<Slot> &slots = *pool;
     int32_t fatal = JPEGAMD_OK;
-    for (size_t k = 0; k < slots.size(); ++k) { slots[k].next_file = (int)k; slots[k].stride = (int)slots.size(); }
-    for (Slot &s : slots) {
+    for (size_t k = 0; k < nslots; ++k) {
+        Slot &s = slots[k];
+        s.next_file = (int)k; s.stride = (int)nslots; s.staged = -1; s.file = -1; s.h2d_pending = false;
+        if (s.stream) continue;                                     // set up by an earlier call
         if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&s.size_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.h2d_done, hipEventDisableTiming) != hipSuccess ||
@@ -245,20 +281,20 @@ extern "C" int32_t jpegamd_encode_files(const char *const *in_paths, const char 
         for (int t = 0; t < nreaders; ++t)
             readers.emplace_back([&, t] {
                 hipSetDevice(dev);
-                for (int i = t; i < count; i += nreaders) stage_file(slots[(size_t)i % slots.size()], i, in_paths[i], &read_ns);
+                for (int i = t; i < count; i += nreaders) stage_file(slots[(size_t)i % nslots], i, in_paths[i], &read_ns);
             });
         for (int i = 0; i < count; ++i) {
-            Slot &s = slots[(size_t)i % slots.size()];
+            Slot &s = slots[(size_t)i % nslots];
             finish_slot(s);                                        // the slot's previous file (i - slots) must be out first
             const int32_t rc = submit(s, i, quality);
             if (rc) { if (status) status[i] = rc; ++failed; continue; }
             s.file = i;
         }
-        for (size_t k = 0; k < slots.size(); ++k) finish_slot(slots[((size_t)count + k) % slots.size()]);   // oldest first
+        for (size_t k = 0; k < nslots; ++k) finish_slot(slots[((size_t)count + k) % nslots]);   // oldest first
         for (std::thread &t : readers) t.join();
         bs.seconds_read = (double)read_ns.load() * 1e-9;
     }
-    for (Slot &s : slots) s.release();
+    if (fatal) for (Slot &s : slots) s.release();                  // (a half-built pool is not kept)
     bs.seconds_total = now_s() - t_begin;
     bs.files_failed = failed;
     if (stats) *stats = bs;
