@@ -344,10 +344,10 @@ static int launch_transform_and_entropy(JpegAmdEncoder *e, const ImageDesc &im, 
     ea.tile_head = e->tile_head; ea.tile_over = e->tile_over;
     ea.huff = e->huff; ea.num_segs = im.num_segs; ea.segs_per_row = im.segs_per_row; ea.tiles_per_row = im.tiles_per_row;
     ea.seg_tiles = im.seg_tiles;
-    e->seg.words_stride = (uint32_t)seg_cap_words(im.seg_tiles);
     ea.seg_begin = im.seg_begin; ea.seg_end = im.seg_end;
     ea.tiles_per_image = im.batch > 1 ? im.num_tiles : 0;
     ea.seg = e->seg;
+    ea.seg.words_stride = (uint32_t)seg_cap_words(im.seg_tiles);       // (the stride follows the launch's segment length: carried in the arguments, the context keeps none)
     ea.status = &e->stats_dev->status;
     return launch_segment_merge(ea, stream, ev ? (void *const *)(ev + 2) : nullptr);
 }
@@ -357,6 +357,7 @@ static int run_finalize_batch(JpegAmdEncoder *e, const ImageDesc &im, void *cons
     FinalizeArgs fa;
     std::memset(&fa, 0, sizeof(fa));
     fa.seg = e->seg;
+    fa.seg.words_stride = (uint32_t)seg_cap_words(im.seg_tiles);
     fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
     fa.batch = im.batch;
     fa.use_groups = (im.num_segs % kSegGroup == 0) ? 1 : 0;      // every image then starts on a group boundary
@@ -408,6 +409,7 @@ static int run_finalize(JpegAmdEncoder *e, const ImageDesc &im, void *out_dev, u
     FinalizeArgs fa;
     std::memset(&fa, 0, sizeof(fa));
     fa.seg = e->seg;
+    fa.seg.words_stride = (uint32_t)seg_cap_words(im.seg_tiles);
     fa.num_segs = im.num_segs; fa.num_chunks = finalize_chunks(im.num_segs);
     fa.batch = 1;
     fa.use_groups = groups_valid ? 1 : 0;       // (segments imported from other ranks have no group aggregates)
@@ -461,8 +463,8 @@ static int32_t exchange_args(JpegAmdEncoder *e, const JpegAmdImage *img, int32_t
     if (rc) return rc;
     if (!dense || !meta) return JPEGAMD_ERR_ARG;
     std::memset(x, 0, sizeof(*x));
-    e->seg.words_stride = (uint32_t)kSegCapWords;          // (the sharded path uses the standard segment length)
     x->seg = e->seg;
+    x->seg.words_stride = (uint32_t)kSegCapWords;           // (the sharded path uses the standard segment length)
     x->s0 = by0 * im.segs_per_row; x->s1 = by1 * im.segs_per_row;
     x->dense = dense; x->dense_cap_words = cap; x->meta = meta; x->total_words = total;
     x->status = &e->stats_dev->status;
@@ -501,7 +503,6 @@ extern "C" int32_t jpegamd_finalize_async(JpegAmdEncoder *e, const JpegAmdImage 
     rc = prepare_constants(e, img, with_container != 0);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    e->seg.words_stride = (uint32_t)kSegCapWords;
     if (run_finalize(e, im, out_dev, out_capacity, out_size_dev, with_container, stream)) return JPEGAMD_ERR_HIP;
     e->last_segs = im.num_segs;
     e->last_stream = stream;

@@ -159,6 +159,8 @@ struct TileSched {            // division-free launch geometry, filled by launch
 // jpegamd_internal.h), the LDS write, the address increment (5 issue slots; the compiler's version costs 4 slots for a site
 // no lane uses and ~10, with a taken branch, for the others).  `addr` is the byte address in LDS of the lane's next item,
 // `zg` the zigzag position of the group's site 0; values are modified in place.
+// (skipping a site no lane of the wave uses -- s_cbranch_execz behind the compare, a third of the sites of an active group -- was
+// measured: no difference, 379.0 / 376.7 vs 378.4 / 377.7 us per launch of eight; profiles/r04_notes_experiments.txt)
 #define JPEGAMD_APPEND_SITE(V, J)                                                                                       \
     "v_cmpx_ne_u32_e32 0, %[" #V "]\n\t"                                                                                \
     "v_add_u32_sdwa %[" #V "], %[zg], " #J " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
