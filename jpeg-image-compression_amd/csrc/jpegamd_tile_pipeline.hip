@@ -42,10 +42,6 @@ namespace jpegamd {
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-#ifndef JPEGAMD_AFR_BATCH
-#define JPEGAMD_AFR_BATCH 2
-#endif
-constexpr int kAfrBatch = JPEGAMD_AFR_BATCH;   // k-steps whose A fragments (2 x 4 VGPRs each) are in registers at once
 #ifndef JPEGAMD_TILE_WG_WAVES
 #define JPEGAMD_TILE_WG_WAVES 8
 #endif
