@@ -157,34 +157,45 @@ struct TileSched {            // division-free launch geometry, filled by launch
 // `zg` the zigzag position of the group's site 0; values are modified in place.
 // (skipping a site no lane of the wave uses -- s_cbranch_execz behind the compare, a third of the sites of an active group -- was
 // measured: no difference, 379.0 / 376.7 vs 378.4 / 377.7 us per launch of eight; profiles/r04_notes_experiments.txt)
-#define JPEGAMD_APPEND_SITE(V, J)                                                                                       \
-    "v_cmpx_ne_u32_e32 0, %[" #V "]\n\t"                                                                                \
+// One site: EXEC is narrowed to the lanes whose value is non-zero (CMP: the compare), the SDWA add writes the site's zigzag position
+// into the upper half of the value's register (the item format of jpegamd_internal.h), the LDS write, the address increment.
+#define JPEGAMD_APPEND_ONE(CMP, V, J)                                                                                   \
+    CMP " 0, %[" #V "]\n\t"                                                                                             \
     "v_add_u32_sdwa %[" #V "], %[zg], " #J " dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t" \
     "ds_write_b32 %[addr], %[" #V "]\n\t"                                                                               \
     "v_add_u32_e32 %[addr], 4, %[addr]\n\t"                                                                            \
     "s_mov_b64 exec, %[save]\n\t"
+// A PAIR of sites lives in one register (low half: site J, high half: site J + 1): the high value moves to a scratch register first
+// (a full-rate right shift), then both go out in site order; the low one is compared as 16 bits.
+#define JPEGAMD_APPEND_PAIR(V, J0, J1)                                                                                  \
+    "v_lshrrev_b32_e32 %[t], 16, %[" #V "]\n\t"                                                                         \
+    JPEGAMD_APPEND_ONE("v_cmpx_ne_u16_e32", V, J0)                                                                      \
+    JPEGAMD_APPEND_ONE("v_cmpx_ne_u32_e32", t, J1)
+#define JPEGAMD_APPEND_HIGH(V, J1)                                                                                      \
+    "v_lshrrev_b32_e32 %[t], 16, %[" #V "]\n\t"                                                                         \
+    JPEGAMD_APPEND_ONE("v_cmpx_ne_u32_e32", t, J1)
+// The four pairs of one group (kSkipFirst: site 0 of group 0 -- the DC item, or zigzag 8 -- was written by the caller).
 template <bool kSkipFirst>
-__device__ __forceinline__ void append_group_lds(uint32_t &addr, int (&v)[8], uint32_t zg) {
+__device__ __forceinline__ void append_group_lds(uint32_t &addr, uint32_t (&v)[4], uint32_t zg) {
     uint64_t save;
+    uint32_t t;
     if (kSkipFirst) {
         asm volatile("s_mov_b64 %[save], exec\n\t"
-                     JPEGAMD_APPEND_SITE(v1, 1) JPEGAMD_APPEND_SITE(v2, 2) JPEGAMD_APPEND_SITE(v3, 3) JPEGAMD_APPEND_SITE(v4, 4)
-                     JPEGAMD_APPEND_SITE(v5, 5) JPEGAMD_APPEND_SITE(v6, 6) JPEGAMD_APPEND_SITE(v7, 7)
-                     : [addr] "+v"(addr), [save] "=&s"(save), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]), [v4] "+v"(v[4]),
-                       [v5] "+v"(v[5]), [v6] "+v"(v[6]), [v7] "+v"(v[7])
+                     JPEGAMD_APPEND_HIGH(v0, 1) JPEGAMD_APPEND_PAIR(v1, 2, 3) JPEGAMD_APPEND_PAIR(v2, 4, 5) JPEGAMD_APPEND_PAIR(v3, 6, 7)
+                     : [addr] "+v"(addr), [save] "=&s"(save), [t] "=&v"(t), [v0] "+v"(v[0]), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3])
                      : [zg] "v"(zg)
                      : "vcc", "memory");
     } else {
         asm volatile("s_mov_b64 %[save], exec\n\t"
-                     JPEGAMD_APPEND_SITE(v0, 0) JPEGAMD_APPEND_SITE(v1, 1) JPEGAMD_APPEND_SITE(v2, 2) JPEGAMD_APPEND_SITE(v3, 3)
-                     JPEGAMD_APPEND_SITE(v4, 4) JPEGAMD_APPEND_SITE(v5, 5) JPEGAMD_APPEND_SITE(v6, 6) JPEGAMD_APPEND_SITE(v7, 7)
-                     : [addr] "+v"(addr), [save] "=&s"(save), [v0] "+v"(v[0]), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]),
-                       [v4] "+v"(v[4]), [v5] "+v"(v[5]), [v6] "+v"(v[6]), [v7] "+v"(v[7])
+                     JPEGAMD_APPEND_PAIR(v0, 0, 1) JPEGAMD_APPEND_PAIR(v1, 2, 3) JPEGAMD_APPEND_PAIR(v2, 4, 5) JPEGAMD_APPEND_PAIR(v3, 6, 7)
+                     : [addr] "+v"(addr), [save] "=&s"(save), [t] "=&v"(t), [v0] "+v"(v[0]), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3])
                      : [zg] "v"(zg)
                      : "vcc", "memory");
     }
 }
-#undef JPEGAMD_APPEND_SITE
+#undef JPEGAMD_APPEND_PAIR
+#undef JPEGAMD_APPEND_HIGH
+#undef JPEGAMD_APPEND_ONE
 
 // ---- the coder ---------------------------------------------------------------------------------------------------------
 // item -> code table entry + left-aligned bit string (Huffman code, then amplitude bits: huffman.c:145-153,176-186).
@@ -454,60 +465,51 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         // groups are dead in two tiles of three, the test on their hi sums runs beside the lower half's MFMAs, and a dead upper half
         // never runs its lo chain (4 of the 16 MFMAs; an MFMA costs the SIMD's vector side 10-20 cycles beside three other waves,
         // profiles/r04_ubench_mfma_overlap.txt).
-        bool gact[4];
-        gact[0] = true;
-        run_chain(1, 1);
-        run_chain(1, 0);
-        gact[2] = group_alive(2);
-        gact[3] = group_alive(3);
-        run_chain(0, 0);
-        if (kTaps || gact[2] || gact[3]) run_chain(0, 1);
-
-        // (the luma stash behind the MFMAs' operand reads instead of in front of them keeps the 16 operand registers alive into
-        //  the quantiser: 15 spilled registers, 8 % slower)
-        TSTAMP(3);   // MFMA
-        const uint32_t ticket_v = ticket();          // (requested here, collected behind the counts: at the top of the iteration or behind the luma
-                                                     //  conversion measured 1.2 % slower -- a wave then sits longer on a reserved, unstarted tile at the end)
         // ---- 3. quantise with the guard band, one GROUP of 8 sites at a time -----------------------
         // Site s = 16H + r of lane (h, b) holds zigzag position 16 * (s >> 3) + 8 * h + (s & 7): group G = s >> 3
-        // covers zigzag 16G .. 16G + 15 across the two lanes of a block.  Every instruction of any wave costs one
-        // 4-cycle issue slot of its SIMD (measured: +256 scalar or vector instructions per tile both cost +16 us),
-        // so the kernel is bound by its instruction count, and in photo-like content most tiles have NO non-zero
+        // covers zigzag 16G .. 16G + 15 across the two lanes of a block.  In photo-like content most tiles have NO non-zero
         // coefficient in the higher groups: one max|acc| test (5 instructions) skips the quantiser, the counts
         // and the appends of such a group (11+ instructions per site).
+        // The quantised values live as PACKED int16 pairs -- n2[p]: site 2p in the low half, site 2p + 1 in the high half (16 registers
+        // instead of 32: what a fifth wave per SIMD needs).  A value is the low half of fma(sum, multiplier, 1.5 * 2^23): round-to-
+        // nearest-even of z, which differs from floor(z + 0.5 + delta) only inside the flagged band, where the exact-order path
+        // overwrites it anyway; the fraction that decides the flag still comes from z + 0.5 + delta_z.
 #define JPEGAMD_ACC(site) (acc[1][(site) >> 4][(site) & 15] + acc[0][(site) >> 4][(site) & 15])     /* hi chain + lo chain */
-        int n[32];
+        uint32_t n2[16];
         uint32_t flagbits = 0;                                      // bit s: site s of this lane is within delta of a rounding tie
-#pragma unroll
-        for (int G = 0; G < 4; ++G) {
-            if (G == 1) gact[1] = group_alive(1);
+        bool gact[4];
+        gact[0] = true;
+        const auto quantise_group = [&](const int G) {
             if (gact[G]) {
                 float a8[8];                                        // the group's LUT sums (times kMfmaScale)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a8[j] = JPEGAMD_ACC(8 * G + j);
                 float fr[8];
+                uint32_t tv[8];
                 // DC (zigzag 0: site 0 of lanes h == 0).  Its LUT sum S is an exact integer and the reference's value has a closed form,
                 // sign(S) floor((|S| + 4 q) / 8 q): the scale 0.25 * 0.707107^2 lies 6.2e-7 ABOVE 1/8, which pushes the ties S = 4 q (2 m + 1)
                 // away from zero by ten float32 steps and nothing else across a tie (checked for every S and every q in 1 .. 255 by
                 // tests/test_host.py::test_dc_closed_form).  floor(|z| + 0.5 + delta) is that value, so the DC lanes quantise |S|,
-                // take the sign afterwards and never flag: rounds 1-2 flagged one DC in 128 (z is a multiple of ~1/128 at Q=50) and
-                // recomputed it in the reference's own operations -- 22 % of the tiles ran the flag compares and a float division for it.
+                // take the sign afterwards and never flag.
                 const unsigned long long dc_lanes = 0x00000000FFFFFFFFull;
                 float a0 = a8[0];
                 if (G == 0) asm("v_cndmask_b32_e64 %0, %1, |%1|, %2" : "=v"(a0) : "v"(a8[0]), "s"(dc_lanes));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int st = 8 * G + j;
                     const float2 q = reinterpret_cast<const float2 *>(q_lane)[16 * G + j];
-                    const float zc = fmaf(j == 0 ? a0 : a8[j], q.x, q.y);   // z + 0.5 + delta_z (three VGPR operands: the 2-cycle form, profiles/r02_issue_model_forms.txt)
-                    n[st] = floor_to_int(zc);
+                    const float aj = j == 0 ? a0 : a8[j];
+                    const float zc = fmaf(aj, q.x, q.y);            // z + 0.5 + delta_z
                     fr[j] = __builtin_amdgcn_fractf(zc);
+                    if (G == 0 && j == 0) {                         // (site 0 keeps the floor: the DC's closed form is stated for it)
+                        const int sg = (int)(__builtin_bit_cast(uint32_t, a0) ^ __builtin_bit_cast(uint32_t, a8[0])) >> 31;    // -1 in the DC lanes with S < 0
+                        tv[0] = (uint32_t)((floor_to_int(zc) ^ sg) - sg);
+                    } else {
+                        tv[j] = __builtin_bit_cast(uint32_t, fmaf(aj, q.x, 12582912.0f));      // 0x4B400000 + n: the value is the low half
+                    }
                 }
-                if (G == 0) {
-                    const int sg = (int)(__builtin_bit_cast(uint32_t, a0) ^ __builtin_bit_cast(uint32_t, a8[0])) >> 31;    // -1 in the DC lanes with S < 0
-                    n[0] = (n[0] ^ sg) - sg;
-                    asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(fr[0]) : "s"(dc_lanes));                                // a DC is never flagged
-                }
+                if (G == 0) asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(fr[0]) : "s"(dc_lanes));                            // a DC is never flagged
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) n2[4 * G + p2] = __builtin_amdgcn_perm(tv[2 * p2 + 1], tv[2 * p2], 0x05040100u);
                 // Flags are rare (0.4 per tile): one min tree over the fractions against the group's largest threshold decides
                 // for the whole wave whether the per-site compares (16 instructions) are needed at all.
                 const float fmin8 = fminf(fminf(__builtin_fminf(fr[0], fminf(fr[1], fr[2])), fminf(fr[3], fminf(fr[4], fr[5]))), fminf(fr[6], fr[7]));
@@ -519,9 +521,34 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 }
             } else if (kTaps) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) n[8 * G + j] = 0;
+                for (int p2 = 0; p2 < 4; ++p2) n2[4 * G + p2] = 0u;
             }
+        };
+        // The transform in two halves of 32 matrix rows, the UPPER rows (zigzag 32..63: groups 2 and 3) first: one half's two
+        // accumulator chains are 32 registers.  In photo-like content the upper groups are dead in two tiles of three: the test on their
+        // hi sums decides whether the half's lo chain runs at all (4 of the 16 MFMAs; an MFMA costs the SIMD's vector side 10-20 cycles
+        // beside the other waves, profiles/r04_ubench_mfma_overlap.txt).  The lower half's B operands are re-read from the luma stash.
+        run_chain(1, 1);
+        gact[2] = group_alive(2);
+        gact[3] = group_alive(3);
+        if (kTaps || gact[2] || gact[3]) run_chain(0, 1);
+        quantise_group(2);
+        quantise_group(3);
+        {
+            uint32_t sl2;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl2));
+            const uint32_t *const sp1 = &s_pix[wave][(sl2 >> 5) * 132 + (sl2 & 31) * 4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) bfrag[s4] = *reinterpret_cast<const f16x8 *>(&sp1[2 * s4 * 132]);
         }
+        run_chain(1, 0);
+        run_chain(0, 0);
+        TSTAMP(3);   // MFMA (+ the upper half's quantiser)
+        const uint32_t ticket_v = ticket();          // (requested here, collected behind the counts: at the top of the iteration or behind the luma
+                                                     //  conversion measured 1.2 % slower -- a wave then sits longer on a reserved, unstarted tile at the end)
+        gact[1] = group_alive(1);
+        quantise_group(0);
+        quantise_group(1);
         if (!active) flagbits = 0u;
         TSTAMP(4);   // quantise
 
@@ -593,14 +620,17 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                         asm volatile("v_mov_b32 %1, %2\n\tv_cndmask_b32_e64 %0, %0, %1, %3" : "+v"(fixval), "=&v"(vtmp) : "s"(ve), "s"(me[e]));
                     }
                 }
+                const uint32_t fix2 = __builtin_amdgcn_perm((uint32_t)fixval, (uint32_t)fixval, 0x05040100u);      // the value in both halves
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     if (__ballot((low >> (8 * G)) & 0xFFu) == 0ull) continue;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {               // (asm: the compiler's version is and + compare + wait state + select)
-                        int m;
-                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(low), "n"(8 * G + j));
-                        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(n[8 * G + j]) : "v"(m), "v"(fixval));
+                    for (int p2 = 0; p2 < 4; ++p2) {            // (asm: the compiler's version is and + compare + wait state + select)
+                        int m0, m1;
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(low), "n"(8 * G + 2 * p2));
+                        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(low), "n"(8 * G + 2 * p2 + 1));
+                        const uint32_t m = __builtin_amdgcn_perm((uint32_t)m1, (uint32_t)m0, 0x05040100u);
+                        asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(n2[4 * G + p2]) : "v"(m), "v"(fix2));
                     }
                 }
                 flagbits ^= low;
@@ -611,7 +641,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             const size_t blk = (size_t)by * im.blocks_w + bx;
             if (out.tap_zz) {
 #pragma unroll
-                for (int st = 0; st < 32; ++st) out.tap_zz[blk * 64 + 16 * (st >> 3) + 8 * h + (st & 7)] = (int16_t)n[st];
+                for (int st = 0; st < 32; ++st) out.tap_zz[blk * 64 + 16 * (st >> 3) + 8 * h + (st & 7)] = (int16_t)(n2[st >> 1] >> (16 * (st & 1)));
             }
             if (out.tap_mask) atomicOr((unsigned long long *)&out.tap_mask[blk], (unsigned long long)exact_mask);
         }
@@ -619,21 +649,24 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 
         // ---- 5. symbol counts per (lane, group), packed one byte per group -> list positions ---------
         // A block's list is ordered by zigzag position: group 0 of lane h=0, group 0 of lane h=1, group 1 of h=0, ...
-        const bool eob = (h == 1) && (gact[3] ? (n[31] == 0) : true);             // rle.c:121-123 (zigzag 63)
+        const bool eob = (h == 1) && (gact[3] ? ((n2[15] >> 16) == 0u) : true);    // rle.c:121-123 (zigzag 63)
         uint32_t cnt = (h == 0) ? 1u : 0u;                                          // the DC item
+        {
+            uint32_t hh = (uint32_t)h;
+            asm volatile("" : "+v"(hh));
+            const uint32_t dc_off = hh ? 0xFFFFFFFFu : 0xFFFF0000u;                  // the DC (site 0 of the lanes h == 0) is not an AC symbol
+            const uint32_t ones = 0x00010001u;
 #pragma unroll
-        for (int G = 0; G < 4; ++G) {
-            if (!gact[G]) continue;
-            int vv[8];
+            for (int G = 0; G < 4; ++G) {
+                if (!gact[G]) continue;
+                // non-zero values of the group: min(v as unsigned, 1) on both halves of a pair at once, summed by plain (full-rate) adds
+                uint32_t f[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vv[j] = (G == 0 && j == 0) ? (h ? n[0] : 0) : n[8 * G + j];   // DC is not an AC symbol
-            // non-zero values of the group: min(|v| as unsigned, 1) summed by three-operand adds -- 12 instructions against the 16 of a
-            // compare / add-with-carry pair per site
-            uint32_t f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm("v_min_u32_e32 %0, 1, %1" : "=v"(f[j]) : "v"(vv[j]));      // (asm: the compiler turns min(x, 1) back into compare + select + wait state)
-            const uint32_t c = (f[0] + f[1] + f[2]) + (f[3] + f[4] + f[5]) + (f[6] + f[7]);
-            cnt += c << (8 * G);
+                for (int p2 = 0; p2 < 4; ++p2) asm("v_pk_min_u16 %0, %1, %2" : "=v"(f[p2]) : "v"(n2[4 * G + p2]), "s"(ones));
+                if (G == 0) f[0] &= dc_off;
+                const uint32_t c2 = (f[0] + f[1]) + (f[2] + f[3]);                  // (low half: even sites, high half: odd sites; <= 4 each)
+                cnt += __builtin_amdgcn_sad_u8(c2, 0u, 0u) << (8 * G);
+            }
         }
         cnt += eob ? (1u << 24) : 0u;
         if (!active) cnt = 0u;
@@ -649,9 +682,11 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 
         // DC prediction inside the tile (rle.c:59-70).  The DC of the tile's FIRST block needs the last block of the tile before:
         // a padding item holds its place in the list, k_segment_merge codes the symbol from the two tiles' records.
-        const int pred = lane_shift_up1(n[0]);
-        const uint32_t dc_item = (b == 0) ? kItPadValue : (uint32_t)((n[0] - pred) & 0xFFFF);
-        const int first_dc = __builtin_amdgcn_readlane(n[0], 0), last_dc = __builtin_amdgcn_readlane(n[0], nblk - 1);
+        int n0;                                                                     // site 0: the DC in the lanes h == 0
+        asm("v_bfe_i32 %0, %1, 0, 16" : "=v"(n0) : "v"(n2[0]));
+        const int pred = lane_shift_up1(n0);
+        const uint32_t dc_item = (b == 0) ? kItPadValue : (uint32_t)((n0 - pred) & 0xFFFF);
+        const int first_dc = __builtin_amdgcn_readlane(n0, 0), last_dc = __builtin_amdgcn_readlane(n0, nblk - 1);
         TSTAMP(6);   // counts + scans
 
         // The ticket requested behind the MFMAs is collected here, BEFORE any younger memory operation is issued
@@ -707,17 +742,17 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                         // site 0: the DC item (always stored) in lanes h == 0, zigzag 8 in lanes h == 1
                         uint32_t first_item = dc_item;
                         if (h) {
-                            first_item = (uint32_t)n[0];
+                            first_item = (uint32_t)n0 & 0xFFFFu;
                             asm("v_add_u32_sdwa %0, %1, 0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
                                 : "+v"(first_item) : "v"(zg));
                         }
-                        if (h == 0 || n[0] != 0) {
+                        if (h == 0 || n0 != 0) {
                             asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(first_item) : "memory");
                             addr += 4u;
                         }
-                        append_group_lds<true>(addr, reinterpret_cast<int (&)[8]>(n[0]), zg);
+                        append_group_lds<true>(addr, reinterpret_cast<uint32_t (&)[4]>(n2[0]), zg);
                     } else {
-                        append_group_lds<false>(addr, reinterpret_cast<int (&)[8]>(n[8 * G]), zg);
+                        append_group_lds<false>(addr, reinterpret_cast<uint32_t (&)[4]>(n2[4 * G]), zg);
                     }
                 }
                 if (eob) {
