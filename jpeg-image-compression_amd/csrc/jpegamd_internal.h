@@ -44,8 +44,8 @@ constexpr uint32_t kItPadValue = 0xF001u;
 // The EOB item (rle.c:121-123) in the same style: size 13, amplitude bits all zero (value -8191); row 0 of the code table
 // holds the EOB code under "size 13".
 constexpr uint32_t kItEobValue = 0xE001u;
-constexpr int kStageItemCap = 8 * 132;          // items a wave's LDS region holds (the tile's dead luma stash): 1056 >= 16 blocks x 65
-constexpr int kStageWords = 1152;               // ... and its size: the list is padded to whole passes of 128 items
+constexpr int kStageWords = 8 * 132;            // a wave's LDS region: the tile's luma stash (8 rows of 132 words), then -- the stash dead -- its item list
+constexpr int kStageItemCap = kStageWords - 128;   // items of one PART of a tile: the list is padded to whole passes of 128 items inside the region (928 >= 8 blocks x 65)
 
 // Code table of k_tile_encode (LDS), built once on the host (quant_consts.cpp: build_code_table), independent of the quality.
 // Entry (row r, fb) at word kCodeLead + 33 r + fb (odd row stride: symbols of one size and different runs sit in different LDS banks):

@@ -141,7 +141,7 @@ constexpr int kWinWords = 256;                                   // bit window p
 constexpr int kWinStr = kWinWords - kTileRecWords;
 constexpr int kPassItems = 128;                                  // items coded per pass: two per lane
 constexpr int kQuadMinItems = 384;                               // lists at least this long try four items per lane first
-static_assert(16 * 65 <= kStageItemCap, "half a tile's items (16 blocks) always fit the staging region");
+static_assert(8 * 65 <= kStageItemCap, "a quarter of a tile's items (8 blocks) always fits the staging region");
 static_assert(kPassItems * (27 + 3 * (int)kZrlBits) / 32 + 6 <= kWinStr && 2 * kPassItems * 27 / 32 + 6 <= kWinStr, "the window takes a whole pass, ZRLs included, and a four-item pass without");
 
 struct TileSched {            // division-free launch geometry, filled by launch_tile_transform
@@ -258,7 +258,6 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     __shared__ float s_qstep[64];
     __shared__ float s_cos[64];
     __shared__ uint32_t s_zz[64];               // zigzag position -> raster index (exact-order path)
-    __shared__ __attribute__((aligned(16))) float s_terms[kWavesT][4 * 64]; // exact-order path: the 64 terms of four coefficients
     // The tile's centred luma (binary16, exact), kept for the exact-order path: row r of block b at word r * 132 + b * 4
     // (528-byte rows: the four 1 KiB stores of a wave and the 64 two-byte reads of one block are conflict-free).
     // Reloading the pixels from HBM instead made every exact-order event wait for vmcnt(0), i.e. for the
@@ -266,6 +265,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     // After the exact-order phase the same words hold the tile's item list.
     __shared__ __attribute__((aligned(16))) uint32_t s_pix[kWavesT][kStageWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_win[kWavesT][kWinWords];      // per wave: the tile's record + bit window; all zero between tiles
+    static_assert(kWinWords == 4 * 64, "the exact-order path parks the 64 terms of four coefficients in the (idle, zero) bit window and zeroes it again");
     __shared__ __attribute__((aligned(16))) uint32_t s_code[kCodeWords];
 #ifdef JPEGAMD_STAMPS
     unsigned long long st_rt0;
@@ -566,7 +566,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             int el;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
             const uint32_t *pix_lane = &s_pix[wave][(el >> 3) * 132 + ((el & 7) >> 1)];
-            float *const terms = &s_terms[wave][0];
+            float *const terms = reinterpret_cast<float *>(&s_win[wave][0]);      // (the window is idle -- and all zero -- until the coder: zeroed again below)
             const float *const my_terms = terms + (el >> 4) * 64;       // lanes 16 e .. 16 e + 15 add up event e of a batch
             // An event = one coefficient recomputed in the reference's own order (dct.c:72-93): lane j forms term j = x * 8 + y, the 64
             // terms go to LDS, and the ordered sum is 64 dependent adds that EVERY lane executes.  Up to four events share those
@@ -636,6 +636,8 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 flagbits ^= low;
                 fm = __ballot(flagbits != 0u);
             } while (__builtin_expect(fm != 0ull, 0));
+#pragma unroll
+            for (int i = 0; i < kWinWords / 64; ++i) s_win[wave][i * 64 + el] = 0u;      // the window as the coder expects it
         }
         if (kTaps && active) {
             const size_t blk = (size_t)by * im.blocks_w + bx;
@@ -720,15 +722,19 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         };
         uint32_t *const stage = &s_pix[wave][0];
         uint32_t *const win = &s_win[wave][0];
-        const int nhalves = t_all <= (uint32_t)kStageItemCap ? 1 : 2;
-        const uint32_t items_h0 = nhalves == 2 ? (uint32_t)__builtin_amdgcn_readlane((int)incl, 15) : t_all;
+        // A list longer than the staging region (noise, very high qualities: up to 65 items per block) is built and coded in PARTS of 16
+        // or 8 blocks each.
+        const uint32_t items_h0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+        const int nparts = t_all <= (uint32_t)kStageItemCap ? 1 : (max(items_h0, t_all - items_h0) <= (uint32_t)kStageItemCap ? 2 : 4);
+        const int part_shift = nparts == 1 ? 5 : (nparts == 2 ? 4 : 3);                 // blocks per part = 1 << part_shift
         uint32_t cur_bits = 0, wbase = 0, nzrl = 0;          // bits of the tile's string so far; string words already in HBM; ZRL symbols
         uint32_t carry_item = 0;                             // the last item of the pass before
 #pragma unroll 1
-        for (int half = 0; half < nhalves; ++half) {             // (one copy of the code: three inlined copies cost more in instruction fetch than the 32 live registers)
-            const uint32_t list_base = half ? items_h0 : 0u;
-            const uint32_t nitems = half ? t_all - items_h0 : items_h0;
-            if (active && (nhalves == 1 || (b >> 4) == half)) {
+        for (int part = 0; part < nparts; ++part) {              // (one copy of the code: inlined copies cost more in instruction fetch than they save)
+            const uint32_t list_base = part ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (part << part_shift) - 1) : 0u;
+            const uint32_t list_end = part == nparts - 1 ? t_all : (uint32_t)__builtin_amdgcn_readlane((int)incl, ((part + 1) << part_shift) - 1);
+            const uint32_t nitems = list_end - list_base;
+            if (active && (b >> part_shift) == part) {
                 const uint32_t stage_addr = (uint32_t)(uintptr_t)stage - list_base * 4u;      // LDS byte address (the low 32 bits of the flat one)
                 uint32_t addr = 0;
                 uint32_t hh8 = (uint32_t)h << 3;               // (opaque: else the four groups' positions are four more loop invariants, spilled)
