@@ -186,6 +186,9 @@ int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float *qthr, flo
  * whose hi-chain LUT sums all stay below grp_thr skips that group's quantiser entirely; lo_bound (may be NULL) is the largest
  * magnitude the lo chain can add to a site of the group -- grp_thr has it taken off. */
 int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr, float *lo_bound);
+/* ... and what the uncentred matrix operand (luma 0 .. 255 as binary16 subnormals) adds: zoff[64] / qadd[64] = bias + zoff by zigzag
+ * position, the DC row's surplus in accumulator units, the accumulator scale.  Any pointer may be NULL. */
+int32_t jpegamd_debug_mfma_offsets(int32_t quality, float *zoff, float *qadd, float *dc_off, float *scale);
 /* The six-decimal cosine table the kernels multiply with, [x][u] (natural_c/src/core/dct.c:9-18), for host-side emulations. */
 int32_t jpegamd_debug_cos_lut(float *lut);
 

@@ -103,6 +103,22 @@ extern "C" int32_t jpegamd_debug_mfma_consts(int32_t quality, float *qmul, float
     return JPEGAMD_OK;
 }
 
+// Host-only: what the UNCENTRED matrix operand adds to the quantiser's constants: qadd = bias + zoff by zigzag position, the DC row's
+// surplus in accumulator units, the accumulator scale (kMfmaScale).
+extern "C" int32_t jpegamd_debug_mfma_offsets(int32_t quality, float *zoff, float *qadd, float *dc_off, float *scale) {
+    uint8_t t[64];
+    MfmaTables *mt = new (std::nothrow) MfmaTables;
+    if (!mt) return JPEGAMD_ERR_HIP;
+    quant_table_for_quality(quality, t);
+    derive_mfma_tables(t, mt, nullptr);
+    if (zoff) std::memcpy(zoff, mt->zoff, sizeof(mt->zoff));
+    if (qadd) std::memcpy(qadd, mt->qadd, sizeof(mt->qadd));
+    if (dc_off) *dc_off = mt->dc_off;
+    if (scale) *scale = kMfmaScale;
+    delete mt;
+    return JPEGAMD_OK;
+}
+
 extern "C" int32_t jpegamd_debug_group_thresholds(int32_t quality, float *grp_thr /*[4 groups][2 lane halves]*/, float *lo_bound /*same shape, may be NULL*/) {
     uint8_t t[64];
     if (!grp_thr) return JPEGAMD_ERR_ARG;

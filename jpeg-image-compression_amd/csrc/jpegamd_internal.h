@@ -30,7 +30,7 @@ constexpr int kMaxBlockBits = 20 + 63 * 27;                          // 1721
 constexpr int seg_cap_words(int seg_tiles) { return ((kTileBlocks * seg_tiles * kMaxBlockBits + 31) / 32 + 1 + 63) / 64 * 64; }   // words reserved per segment
 constexpr int kSegCapWords = seg_cap_words(kSegTiles);
 constexpr int kAFragWords = 2 * 2 * 4 * 64 * 4;                      // [term][chain][kstep][lane] x 8 binary16 = 16 KiB
-constexpr float kMfmaScale = 2048.0f;                                // the accumulator chains hold kMfmaScale * LUT sum (hi chain + lo chain)
+constexpr float kMfmaScale = 1.0f / 8192.0f;                         // the accumulator chains hold kMfmaScale * LUT sum (hi chain + lo chain): the A terms are 2048 K, the B operand is y 2^-24
 
 // Per-tile symbol lists (private to k_tile_encode: built in LDS, coded by the wave that built them, never written out).
 // An item is one symbol-to-be, 4 bytes: bits 15..0 the value (int16), bits 21..16 the zigzag position (the producer writes
@@ -83,6 +83,10 @@ struct MfmaTables {
                                    // (the lo chain's largest possible contribution, lo_bound, is taken off: the test runs ahead of the add that joins the chains)
     float lo_bound[8];             // [group G][lane half h]: max over the sites of |lo-chain output|, in accumulator units
     float flag_thr[8];             // [group G][lane half h]: max qthr over zigzag 16G+8h .. +7
+    float zoff[64];                // by zigzag position: what the quantiser adds besides the bias -- minus (K/q) x the constant the UNCENTRED B operand leaves in the row (five positions; 0 elsewhere)
+    float qadd[64];                // bias + zoff: the additive constant of the quantiser's fma, by zigzag position
+    float dc_off;                  // what the DC row's accumulator holds beyond the centred pixel sum: kMfmaScale * 64 * 128 (= 1.0)
+    float pad[3];
 };
 
 struct ScanStats {                   // device-side per-call record

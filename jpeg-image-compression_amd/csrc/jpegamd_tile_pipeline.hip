@@ -68,38 +68,34 @@ __device__ __forceinline__ LumaWeights luma_weights(uint32_t w /*weights of stor
     return l;
 }
 
-// 8 pixels (24 bytes) -> 8 centred luma values (converter.c:51,84-86) as binary16, the B fragment of one k-step half.
-// Y = (w . rgb) >> 8 is byte 1 of the dot product; with 0xFFFF8000 (= -32768) as the accumulator input that byte IS the
-// centred value as a signed byte, and one v_cvt_f16_i16 with an SDWA byte select converts it straight into its half of
-// the packed register: 12 v_dot4 + 8 converts per 8 pixels (round 1: + 6 packs to bf16 + 4 permutes).  One asm block, so
-// that every convert reads a dot product issued at least three instructions earlier (DOT -> SDWA read hazard on gfx950,
-// which hipcc pads for its own instructions only).
-__device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeights &w, uint32_t kc) {
+// 8 pixels (24 bytes) -> 8 luma values (converter.c:51,84-86) as the B fragment of one k-step half.
+// Y = (w . rgb) >> 8 is byte 1 of the dot product, and the integer Y in a 16-bit half IS the binary16 subnormal Y 2^-24: the matrix pipe
+// takes it at face value (tools/ubench/mfma_denorm.hip), so two dot products are packed by ONE v_perm -- 12 v_dot4 + 4 v_perm per 8
+// pixels (rounds 2-4: 8 v_cvt_f16_i16 with SDWA byte selects on the CENTRED value; round 1: + 6 packs to bf16 + 4 permutes).  The
+// operand is the UNCENTRED luma: the hi terms of every AC row of the matrix add up to zero and the DC row's surplus is a constant
+// (quant_consts.cpp: zoff, dc_off).
+__device__ __forceinline__ f16x8 luma_row8_f16(const RawRow &raw, const LumaWeights &w, uint32_t sel /*0x0C050C01: byte 1 of each source into the halves*/) {
     uint32_t o0, o1, o2, o3, t0, t1, t2, t3, t4, t5, t6, t7;
-    asm("v_dot4_u32_u8 %[t0], %[d0], %[wa], %[kc]\n\t"
-        "v_dot4_u32_u8 %[t1], %[d0], %[wb0], %[kc]\n\t"
-        "v_dot4_u32_u8 %[t2], %[d1], %[wc0], %[kc]\n\t"
-        "v_dot4_u32_u8 %[t3], %[d2], %[wd], %[kc]\n\t"
-        "v_dot4_u32_u8 %[t4], %[d3], %[wa], %[kc]\n\t"
-        "v_dot4_u32_u8 %[t5], %[d3], %[wb0], %[kc]\n\t"
-        "v_dot4_u32_u8 %[t6], %[d4], %[wc0], %[kc]\n\t"
-        "v_dot4_u32_u8 %[t7], %[d5], %[wd], %[kc]\n\t"
+    asm("v_dot4_u32_u8 %[t0], %[d0], %[wa], 0\n\t"
+        "v_dot4_u32_u8 %[t1], %[d0], %[wb0], 0\n\t"
+        "v_dot4_u32_u8 %[t2], %[d1], %[wc0], 0\n\t"
+        "v_dot4_u32_u8 %[t3], %[d2], %[wd], 0\n\t"
+        "v_dot4_u32_u8 %[t4], %[d3], %[wa], 0\n\t"
+        "v_dot4_u32_u8 %[t5], %[d3], %[wb0], 0\n\t"
+        "v_dot4_u32_u8 %[t6], %[d4], %[wc0], 0\n\t"
+        "v_dot4_u32_u8 %[t7], %[d5], %[wd], 0\n\t"
         "v_dot4_u32_u8 %[t1], %[d1], %[wb1], %[t1]\n\t"
         "v_dot4_u32_u8 %[t2], %[d2], %[wc1], %[t2]\n\t"
         "v_dot4_u32_u8 %[t5], %[d4], %[wb1], %[t5]\n\t"
         "v_dot4_u32_u8 %[t6], %[d5], %[wc1], %[t6]\n\t"
-        "v_cvt_f16_i16_sdwa %[o0], sext(%[t0]) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
-        "v_cvt_f16_i16_sdwa %[o1], sext(%[t3]) dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
-        "v_cvt_f16_i16_sdwa %[o2], sext(%[t4]) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
-        "v_cvt_f16_i16_sdwa %[o3], sext(%[t7]) dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:BYTE_1\n\t"
-        "v_cvt_f16_i16_sdwa %[o0], sext(%[t1]) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n\t"
-        "v_cvt_f16_i16_sdwa %[o1], sext(%[t2]) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n\t"
-        "v_cvt_f16_i16_sdwa %[o2], sext(%[t5]) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n\t"
-        "v_cvt_f16_i16_sdwa %[o3], sext(%[t6]) dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1"
+        "v_perm_b32 %[o0], %[t1], %[t0], %[sel]\n\t"
+        "v_perm_b32 %[o1], %[t3], %[t2], %[sel]\n\t"
+        "v_perm_b32 %[o2], %[t5], %[t4], %[sel]\n\t"
+        "v_perm_b32 %[o3], %[t7], %[t6], %[sel]"
         : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
           [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6), [t7] "=&v"(t7)
         : [d0] "v"(raw.d[0]), [d1] "v"(raw.d[1]), [d2] "v"(raw.d[2]), [d3] "v"(raw.d[3]), [d4] "v"(raw.d[4]), [d5] "v"(raw.d[5]),
-          [wa] "s"(w.a), [wb0] "s"(w.b0), [wb1] "s"(w.b1), [wc0] "s"(w.c0), [wc1] "s"(w.c1), [wd] "s"(w.d), [kc] "v"(kc));
+          [wa] "s"(w.a), [wb0] "s"(w.b0), [wb1] "s"(w.b1), [wc0] "s"(w.c0), [wc1] "s"(w.c1), [wd] "s"(w.d), [sel] "v"(sel));
     typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
     const u32x4 packed = {o0, o1, o2, o3};
     return __builtin_bit_cast(f16x8, packed);
@@ -251,7 +247,7 @@ template <bool kTaps>
 __global__ __launch_bounds__(64 * kWavesT) __attribute__((amdgpu_waves_per_eu(JPEGAMD_TILE_WAVES, JPEGAMD_TILE_WAVES)))
 void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched sch) {
     __shared__ __attribute__((aligned(16))) uint32_t s_afrag[kAFragWords];
-    // s_qt[0..127]: (multiplier, bias) by zigzag position; [160 + 16 h + 32 G + j]: flag threshold (2 bias - 1) of zigzag 16 G + 8 h + j; [128 + 16 h + G]: zero threshold of group G for lane half h
+    // s_qt[0..127]: (multiplier, additive constant: bias + zoff) by zigzag position; [136 + 16 h]: the DC row's surplus (h == 0; 0 for h == 1); [160 + 16 h + 32 G + j]: flag threshold (2 bias - 1) of zigzag 16 G + 8 h + j; [128 + 16 h + G]: zero threshold of group G for lane half h
     // (|acc| below it => every site of the group quantises to an unflagged 0), [132 + 16 h + G]: the largest tie threshold of the
     // group's sites (fract(zc) above it => no site is flagged).  One layout with 64 bytes per lane half: one address register.
     __shared__ __attribute__((aligned(16))) float s_qt[128 + 32 + 128];
@@ -284,12 +280,13 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             for (int i = t; i < kCodeWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(s_code)[i] = csrc[i]; \
             for (int i = t; i < kWavesT * kWinWords / 4; i += 64 * kWavesT) reinterpret_cast<uint4 *>(&s_win[0][0])[i] = make_uint4(0u, 0u, 0u, 0u); \
             if (t < 64) { \
-                s_qt[2 * t] = out.tables->qmul[t]; s_qt[2 * t + 1] = out.tables->bias[t]; \
+                s_qt[2 * t] = out.tables->qmul[t]; s_qt[2 * t + 1] = out.tables->qadd[t]; \
                 s_qt[160 + 16 * ((t >> 3) & 1) + 32 * (t >> 4) + (t & 7)] = out.tables->qthr[t]; \
                 s_qstep[t] = out.tables->qstep[t]; \
                 s_cos[t] = kCosFM[t]; \
                 s_zz[t] = kZZ[t]; \
                 if (t < 8) { s_qt[128 + 16 * (t & 1) + (t >> 1)] = out.tables->grp_thr[t]; s_qt[132 + 16 * (t & 1) + (t >> 1)] = out.tables->flag_thr[t]; } \
+                if (t < 2) s_qt[136 + 16 * t] = t ? 0.0f : out.tables->dc_off; \
             } \
         } \
         __syncthreads(); \
@@ -298,7 +295,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: tile indices, list pointers and the buffer descriptor stay on the scalar unit
     const int h = lane >> 5, b = lane & 31;
     const LumaWeights lw = luma_weights(im.weights);
-    const uint32_t luma_kc = 0xFFFF8000u;
+    const uint32_t luma_sel = 0x0C050C01u;
     const float *q_lane = &s_qt[16 * h];
 
     // Persistent waves: tile = first, first + stride, ...  The matrix image is loaded once per workgroup and the
@@ -341,7 +338,16 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
     // This launch's counters were zeroed by the previous launch on this context; zero the next launch's (the other set).
     if (bid == 0 && threadIdx.x < kTileGroups) out.tile_ctr_next[threadIdx.x * 32] = 0u;   // all of them: the next launch may form more groups
     const int first = (bid >> sch.grp_shift) * kWavesT + wave;
-    const auto ticket = [&]() -> uint32_t { return lane == 0 ? atomicAdd(ctr, 1u) : 0u; };
+    // One lane draws the ticket: EXEC = 1 around the atomic (no lane mask to keep in two scalar registers across the loop).  The result is
+    // collected behind an explicit s_waitcnt vmcnt(0) -- the compiler does not count this operation (it then waits for one more than it
+    // thinks wherever it waits: safe).
+    const auto ticket = [&]() -> uint32_t {
+        uint32_t r = 0u, one = 1u, zero = 0u;
+        uint64_t save;
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %[r], %[z], %[one], %[p] sc0\n\ts_mov_b64 exec, %[sv]"
+                     : [r] "+v"(r), [sv] "=&s"(save) : [z] "v"(zero), [one] "v"(one), [p] "s"(ctr) : "memory");
+        return r;
+    };
     struct TileGeo { int img, by, tbx0, nblk, interior; };      // (no padding bytes: a bool at the end made the copy of the struct carry three of them through scratch)
     const auto geo = [&](int tile) {
         TileGeo g;
@@ -357,7 +363,9 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         g.by = q;
         g.tbx0 = r * kTileBlocks;
         g.nblk = min(kTileBlocks, im.blocks_w - g.tbx0);
-        g.interior = im.fast_ok && ((g.tbx0 + g.nblk) * 8 <= im.width) && (g.by * 8 + 8 <= im.height);
+        // (integer arithmetic: as booleans the three conditions meet in lane masks and come back through a v_cndmask and a v_readfirstlane)
+        const int over_x = (im.width - (g.tbx0 + g.nblk) * 8) >> 31, over_y = (im.height - (g.by * 8 + 8)) >> 31;      // -1: beyond the picture
+        g.interior = (im.fast_ok != 0 ? 1 : 0) & ~(over_x | over_y);
         return g;
     };
     // Interior tiles: a scalar base (lowest-address row of the tile's 8, first block) plus 32-bit lane offsets --
@@ -405,14 +413,19 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         f16x8 bfrag[4];
         if (interior) {                        // rows requested one iteration ago, behind the ticket (below)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_f16(raw[s], lw, luma_kc);
+            for (int s = 0; s < 4; ++s) bfrag[s] = luma_row8_f16(raw[s], lw, luma_sel);
         } else {
             // edge tile (right/bottom replication, converter.c:31,36) or unaligned source: clamped byte gather
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
+                u32x4 pk;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    bfrag[s][j] = (_Float16)(float)(luma_clamped(im, im.batch_pixels[tg.img], px0 + j, py0 + 2 * s + h) - 128);
+                for (int j = 0; j < 8; j += 2)                  // two values per register: Y in each 16-bit half (= Y 2^-24 as binary16, as above)
+                    pk[j >> 1] = (uint32_t)luma_clamped(im, im.batch_pixels[tg.img], px0 + j, py0 + 2 * s + h) |
+                                 ((uint32_t)luma_clamped(im, im.batch_pixels[tg.img], px0 + j + 1, py0 + 2 * s + h) << 16);
+                bfrag[s] = __builtin_bit_cast(f16x8, pk);
+            }
         }
         TSTAMP(1);   // wait for the prefetched rows + luma
         {
@@ -425,10 +438,13 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         TSTAMP(2);   // luma -> LDS
         if (kTaps && active && out.tap_y) {
             int8_t *ty = out.tap_y + ((size_t)by * im.blocks_w + bx) * 64;
+            typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
+                const u32x4 pk = __builtin_bit_cast(u32x4, bfrag[s]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ty[(2 * s + h) * 8 + j] = (int8_t)(int)(float)bfrag[s][j];
+                for (int j = 0; j < 8; ++j) ty[(2 * s + h) * 8 + j] = (int8_t)((int)((pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) - 128);     // converter.c:51: the centred value
+            }
         }
 
         // ---- 2. the 64x64 transform on the matrix pipe ------------------------------------------
@@ -455,11 +471,13 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         };
         // Is any site of group G alive?  |sum| below the group's zero threshold in every lane => every site quantises to an
         // unflagged 0.  Tested on the hi chain alone (the threshold has the lo chain's bound taken off).
-        const auto group_alive = [&](const int G) -> bool {
+        const auto group_alive = [&](const int G) -> int {
             float m = fmaxf(fabsf(acc[1][(8 * G) >> 4][(8 * G) & 15]), fabsf(acc[1][(8 * G + 1) >> 4][(8 * G + 1) & 15]));
 #pragma unroll
             for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(acc[1][(8 * G + j) >> 4][(8 * G + j) & 15]));
-            return __ballot(m >= q_lane[128 + G]) != 0ull;
+            int alive = (int)__popcll(__ballot(m >= q_lane[128 + G]));      // (a scalar count, not a lane mask: tested by s_cmp where it is used)
+            asm volatile("" : "+s"(alive));
+            return alive;
         };
         // The hi chains first, the upper matrix rows (zigzag 32..63: groups 2 and 3) ahead of the lower ones: in photo-like content those
         // groups are dead in two tiles of three, the test on their hi sums runs beside the lower half's MFMAs, and a dead upper half
@@ -477,13 +495,17 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 #define JPEGAMD_ACC(site) (acc[1][(site) >> 4][(site) & 15] + acc[0][(site) >> 4][(site) & 15])     /* hi chain + lo chain */
         uint32_t n2[16];
         uint32_t flagbits = 0;                                      // bit s: site s of this lane is within delta of a rounding tie
-        bool gact[4];
-        gact[0] = true;
+        int gact[4];
+        gact[0] = 1;
+        // (read through a scalar the compiler cannot trace at every use: else each flag becomes a lane mask AND its negation, made by
+        //  two vector instructions, held in two register pairs)
+        const auto alive = [&](const int G) -> bool { int g = gact[G]; asm volatile("" : "+s"(g)); return g != 0; };
         const auto quantise_group = [&](const int G) {
-            if (gact[G]) {
+            if (G == 0 || alive(G)) {
                 float a8[8];                                        // the group's LUT sums (times kMfmaScale)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a8[j] = JPEGAMD_ACC(8 * G + j);
+                if (G == 0) a8[0] -= q_lane[136];                   // the DC row holds the UNCENTRED pixel sum: 64 x 128 (1.0 in accumulator units) too much; exact.  (lanes h == 1: 0)
                 float fr[8];
                 uint32_t tv[8];
                 // DC (zigzag 0: site 0 of lanes h == 0).  Its LUT sum S is an exact integer and the reference's value has a closed form,
@@ -491,9 +513,11 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 // away from zero by ten float32 steps and nothing else across a tie (checked for every S and every q in 1 .. 255 by
                 // tests/test_host.py::test_dc_closed_form).  floor(|z| + 0.5 + delta) is that value, so the DC lanes quantise |S|,
                 // take the sign afterwards and never flag.
-                const unsigned long long dc_lanes = 0x00000000FFFFFFFFull;
+                // (the mask of the DC lanes, 0x00000000FFFFFFFF, is made where it is used: one scalar move instead of a register pair held
+                //  across the whole loop)
+                unsigned long long dc_lanes;
                 float a0 = a8[0];
-                if (G == 0) asm("v_cndmask_b32_e64 %0, %1, |%1|, %2" : "=v"(a0) : "v"(a8[0]), "s"(dc_lanes));
+                if (G == 0) asm("s_mov_b64 %1, 0xffffffff\n\tv_cndmask_b32_e64 %0, %2, |%2|, %1" : "=v"(a0), "=&s"(dc_lanes) : "v"(a8[0]));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float2 q = reinterpret_cast<const float2 *>(q_lane)[16 * G + j];
@@ -507,7 +531,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                         tv[j] = __builtin_bit_cast(uint32_t, fmaf(aj, q.x, 12582912.0f));      // 0x4B400000 + n: the value is the low half
                     }
                 }
-                if (G == 0) asm("v_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(fr[0]) : "s"(dc_lanes));                            // a DC is never flagged
+                if (G == 0) asm("s_mov_b64 %1, 0xffffffff\n\tv_cndmask_b32_e64 %0, %0, 1.0, %1" : "+v"(fr[0]), "=&s"(dc_lanes));           // a DC is never flagged
 #pragma unroll
                 for (int p2 = 0; p2 < 4; ++p2) n2[4 * G + p2] = __builtin_amdgcn_perm(tv[2 * p2 + 1], tv[2 * p2], 0x05040100u);
                 // Flags are rare (0.4 per tile): one min tree over the fractions against the group's largest threshold decides
@@ -531,7 +555,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         run_chain(1, 1);
         gact[2] = group_alive(2);
         gact[3] = group_alive(3);
-        if (kTaps || gact[2] || gact[3]) run_chain(0, 1);
+        if (kTaps || (gact[2] | gact[3]) != 0) run_chain(0, 1);
         quantise_group(2);
         quantise_group(3);
         {
@@ -592,7 +616,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                             const int z = 16 * (st >> 3) + 8 * (fl >> 5) + (st & 7);
                             const int k = __builtin_amdgcn_readfirstlane((int)s_zz[z]), u = k >> 3, v = k & 7;
                             const uint32_t pw = pix_lane[(fl & 31) * 4];
-                            const float pix = (float)__builtin_bit_cast(_Float16, (uint16_t)((el & 1) ? pw >> 16 : pw));
+                            const float pix = (float)((int)((el & 1) ? pw >> 16 : pw & 0xFFFFu) - 128);      // the stash holds Y; the reference sums Y - 128
                             const float cx = s_cos[u * 8 + (el >> 3)];     // COS_LUT[x][u]
                             const float cy = s_cos[v * 8 + (el & 7)];      // COS_LUT[y][v]
                             terms[e * 64 + el] = __fmul_rn(__fmul_rn(pix, cx), cy);             // dct.c:84
@@ -651,7 +675,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
 
         // ---- 5. symbol counts per (lane, group), packed one byte per group -> list positions ---------
         // A block's list is ordered by zigzag position: group 0 of lane h=0, group 0 of lane h=1, group 1 of h=0, ...
-        const bool eob = (h == 1) && (gact[3] ? ((n2[15] >> 16) == 0u) : true);    // rle.c:121-123 (zigzag 63)
+        const bool eob = (h == 1) && (alive(3) ? ((n2[15] >> 16) == 0u) : true);    // rle.c:121-123 (zigzag 63)
         uint32_t cnt = (h == 0) ? 1u : 0u;                                          // the DC item
         {
             uint32_t hh = (uint32_t)h;
@@ -660,7 +684,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
             const uint32_t ones = 0x00010001u;
 #pragma unroll
             for (int G = 0; G < 4; ++G) {
-                if (!gact[G]) continue;
+                if (G && !alive(G)) continue;
                 // non-zero values of the group: min(v as unsigned, 1) on both halves of a pair at once, summed by plain (full-rate) adds
                 uint32_t f[4];
 #pragma unroll
@@ -686,15 +710,19 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         // a padding item holds its place in the list, k_segment_merge codes the symbol from the two tiles' records.
         int n0;                                                                     // site 0: the DC in the lanes h == 0
         asm("v_bfe_i32 %0, %1, 0, 16" : "=v"(n0) : "v"(n2[0]));
-        const int pred = lane_shift_up1(n0);
-        const uint32_t dc_item = (b == 0) ? kItPadValue : (uint32_t)((n0 - pred) & 0xFFFF);
+        int pred = lane_shift_up1(n0);
+        asm volatile("" : "+v"(pred));             // (kept apart from the subtraction: fused into one v_subrev_u32_dpp ... wave_shr:1 the difference came out WRONG on the GPU)
+        uint32_t dc_item = (uint32_t)((n0 - pred) & 0xFFFF);
+        asm("s_nop 1\n\tv_writelane_b32 %0, %1, 0" : "+v"(dc_item) : "s"(kItPadValue));      // lane 0 (the tile's first block) takes the padding item
         const int first_dc = __builtin_amdgcn_readlane(n0, 0), last_dc = __builtin_amdgcn_readlane(n0, nblk - 1);
         TSTAMP(6);   // counts + scans
 
         // The ticket requested behind the MFMAs is collected here, BEFORE any younger memory operation is issued
         // (built with the atomic optimizer off -- its expansion reads the result back, and waits for vmcnt(0), right
         // behind the atomic).
-        int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_v);
+        uint32_t ticket_in = ticket_v;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket_in) :: "memory");
+        int nxt = cur_waves + (int)__builtin_amdgcn_readfirstlane(ticket_in);
         TileGeo tg_next = tg;
         int tile_next = tile;
         if (nxt < cur_hi) { tile_next = to_tile(nxt); tg_next = geo(tile_next); }
@@ -741,7 +769,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                 asm volatile("" : "+v"(hh8));
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
-                    if (!gact[G]) continue;
+                    if (G && !alive(G)) continue;
                     addr = stage_addr + (blk_base + ((starts >> (8 * G)) & 0xFFu)) * 4u;
                     const uint32_t zg = (uint32_t)(16 * G) + hh8;
                     if (G == 0) {
@@ -762,7 +790,7 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
                     }
                 }
                 if (eob) {
-                    if (!gact[3]) addr = stage_addr + (blk_base + (starts >> 24)) * 4u;
+                    if (!alive(3)) addr = stage_addr + (blk_base + (starts >> 24)) * 4u;
                     asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(kItEobValue) : "memory");
                 }
             }

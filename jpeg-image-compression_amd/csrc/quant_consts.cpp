@@ -149,11 +149,20 @@ constexpr double kPmax = 128.0;
 // out_z = sum_p Kmat[c][p] * pix[p], Kmat[c][p] = COS_LUT[x][u] * COS_LUT[y][v] (exact product of the two float32
 // literals), computed by two chains of 4 v_mfma_f32_32x32x16_f16 per row half: Kmat = hi 2^-11 + lo 2^-22 with INTEGER
 // hi = round(2^11 Kmat) (|hi| <= 2048) and lo = round(2^22 (Kmat - hi 2^-11)) (|lo| <= 1024); the hi chain's A entries
-// are hi, the lo chain's are lo 2^-11 (both exact in binary16), pixels (int8) exact in binary16.  With |pix| <= 128 every
-// product and every partial sum of a chain is a multiple of the chain's unit (1, resp. 2^-11) below 2^24 units, so the
-// float32 accumulation is EXACT in any order the hardware adds; the kernel joins the chains with one float add:
-// acc = kMfmaScale * (LUT sum with Kmat replaced by hi 2^-11 + lo 2^-22), one rounding.  derive_mfma_tables verifies the
-// representability and the 2^24 bounds (split_ok) and falls back to "flag everything" if they ever failed.
+// are hi, the lo chain's are lo 2^-11 (both exact in binary16).
+// The B operand is the UNCENTRED luma y = p + 128 in 0 .. 255 as a binary16 SUBNORMAL: the integer y IS the bit pattern of y 2^-24,
+// so the kernel packs two dot-product bytes into a register with one v_perm instead of converting each with v_cvt_f16_i16 (the matrix
+// pipe takes subnormal inputs at face value: tools/ubench/mfma_denorm.hip, profiles/r04_ubench_mfma_denorm.txt).  What makes this
+// free: for every AC position the hi terms of a row sum to ZERO exactly (the LUT's symmetry), so sum hi y = sum hi p, and the lo
+// terms sum to T_lo = 0 for all but five positions (32 units of 2^-22 at (0,3), (3,0), (0,6), (6,0), 1 at (3,3)), whose constant
+// 128 T_lo 2^-22 goes into the quantiser's additive constant (zoff).  The DC row (hi = 2048 everywhere, lo = 0) yields the
+// plain pixel sum, 64 * 128 too large: the kernel takes 1.0 off its accumulator (dc_off; exact).
+// Exactness: with 0 <= y <= 255 every partial sum of a chain lies between -255 * (sum of the negative terms) and 255 * (sum of the
+// positive ones), multiples of the chain's unit below 2^24 units (AC rows: at most 0.71 * 2^24; the DC row's partial sums are
+// multiples of 2048 units), so the float32 accumulation is EXACT in any order the hardware adds; the kernel joins the chains with
+// one float add: acc = kMfmaScale * (LUT sum over y with Kmat replaced by hi 2^-11 + lo 2^-22), one rounding, kMfmaScale = 2^-13.
+// derive_mfma_tables verifies the representability, the zero row sums and the 2^24 bounds (split_ok) and falls back to "flag
+// everything" if they ever failed.
 // (History: round 1 used three bf16 terms in one accumulator, round 2's first kernel two binary16 terms in one accumulator
 // with E_mfma = 2 * 16u * sum_m (|acc before MFMA m| + S_m): 2.3 x the reference's own evaluation error E_ref.)
 namespace {
@@ -190,6 +199,7 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
     for (int z = 0; z < 64; ++z) {
         const int k = kZigzagHost[z], u = k >> 3, v = k & 7;
         double kmat[64], term[2][64], split_res = 0, hi_units = 0, lo_units = 0;     // terms in units of Kmat
+        double hi_pos = 0, hi_neg = 0, lo_pos = 0, lo_neg = 0, hi_sum = 0, lo_sum = 0; // signed parts of a row's terms, in units
         for (int x = 0; x < 8; ++x)
             for (int y = 0; y < 8; ++y) {
                 const int p = x * 8 + y;
@@ -203,6 +213,8 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
                 term[0][p] = lo_i / 4194304.0; term[1][p] = hi_i / 2048.0;
                 split_res += std::fabs(kmat[p] - (term[0][p] + term[1][p]));
                 hi_units += std::fabs(hi_i); lo_units += std::fabs(lo_i);
+                (hi_i > 0 ? hi_pos : hi_neg) += std::fabs(hi_i); (lo_i > 0 ? lo_pos : lo_neg) += std::fabs(lo_i);
+                hi_sum += hi_i; lo_sum += lo_i;
                 // scatter into the A-operand order: term t, chain H, matrix row R, k-step s, lane (hk, R), element j;
                 // lane half h = (z >> 3) & 1 holds z = 16G + 8h + j at site 8G + j = 16H + r
                 const int site = 8 * (z >> 4) + (z & 7);
@@ -218,19 +230,28 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
         for (int j = 0; j < 64; ++j) { const double w = std::fabs(kmat[j]); wsum += w; run += w; if (j >= 1) adds += run; }
         const double e_ref = (2.0 * kU * kPmax * wsum + kU * kPmax * adds) * 1.001;
         // Each chain is exact when every partial sum stays below 2^24 of its units (hi: 1, lo: 2^-11 of the hi unit) whatever the
-        // summation order: |pixel| * sum |term| bounds them all.  What is left of the matrix pipe is the ONE rounding of the add
-        // that joins the chains, relative to |S| <= kPmax * wsum.
-        if (kPmax * hi_units > 16777216.0 || kPmax * lo_units > 16777216.0) split_ok = false;      // (integers up to 2^24 inclusive are float32 values)
-        lo_abs[z] = kPmax * lo_units / 2048.0;              // |lo-chain output| <= this (the terms are stored as lo 2^-11)
+        // summation order: with 0 <= y <= 255 a partial sum lies in [-255 * negative part, 255 * positive part].  (The DC row: every
+        // term is 2048 units, every partial sum a multiple of 2048 below 2^24 * 2048.)  What is left of the matrix pipe is the ONE
+        // rounding of the add that joins the chains, relative to |S| <= kPmax * wsum (the sums themselves are those of the centred
+        // pixels: the hi terms of an AC row add up to zero).
+        const bool dc_row = z == 0;
+        if (dc_row ? (hi_pos != 64.0 * 2048.0 || hi_neg != 0.0 || lo_units != 0.0) : (hi_sum != 0.0)) split_ok = false;
+        if ((!dc_row && 255.0 * std::fmax(hi_pos, hi_neg) > 16777216.0) || 255.0 * std::fmax(lo_pos, lo_neg) > 16777216.0) split_ok = false;   // (integers up to 2^24 inclusive are float32 values)
+        // the constant the uncentred operand leaves in an AC row: 128 * T_lo units of 2^-22 (in units of Kmat)
+        const double c_row = dc_row ? 0.0 : 128.0 * lo_sum / 4194304.0;
+        lo_abs[z] = S * (kPmax * lo_units + 128.0 * std::fabs(lo_sum)) / 4194304.0;               // |lo-chain output| <= this, in accumulator units
         const double e_mfma = kU * kPmax * wsum * 1.0001;
         const float cu = u == 0 ? 0.707107f : 1.0f, cv = v == 0 ? 0.707107f : 1.0f;
         const double K = (double)((0.25f * cu) * cv);
         const double q = (double)table[k];
         const double zmax = K * kPmax * wsum / q;
-        const double delta = (K / q) * (e_ref + e_mfma + kPmax * split_res) + 4.0 * kU * (zmax + 1.0);
+        // (the rounded value comes from fma(acc, qmul, 1.5 * 2^23), which cannot carry the row's constant: it rounds z + (K/q) c_row, and
+        //  that agrees with the rounding of z wherever z is further than |(K/q) c_row| from a tie -- so the band includes it)
+        const double delta = (K / q) * (e_ref + e_mfma + kPmax * split_res + std::fabs(c_row)) + 4.0 * kU * (zmax + 1.0);
+        mt->zoff[z] = (float)(-(K / q) * c_row);
         delta_z[z] = delta;
         if (z > 0 && delta > dmax) dmax = delta;
-        mt->qmul[z] = (float)(K / (q * S));                 // the accumulator holds kMfmaScale * LUT sum
+        mt->qmul[z] = (float)(K / (q * S));                 // the accumulator holds kMfmaScale * LUT sum (a power of two: K / q rounds the same)
         mt->qstep[z] = (float)table[k];
         if (delta_out) delta_out[k] = delta;
     }
@@ -242,16 +263,18 @@ void derive_mfma_tables(const uint8_t table[64], MfmaTables *mt, double delta_ou
         mt->bias[z] = (float)(0.5 + delta_z[z] * 1.001 + 1.0e-7);
         mt->qthr[z] = 2.0f * mt->bias[z] - 1.0f;
     }
+    for (int z = 0; z < 64; ++z) mt->qadd[z] = (float)((double)mt->bias[z] + (double)mt->zoff[z]);      // what the kernel's fma adds
+    mt->dc_off = (float)(S * 64.0 * 128.0);                // what the DC row's accumulator holds beyond the centred sum: kMfmaScale * sum of 64 x 128 (1.0 at 2^-13)
     if (!split_ok)                                          // cannot happen with the reference's LUT; if it did, EVERY coefficient takes the exact-order path
-        for (int z = 0; z < 64; ++z) { mt->bias[z] = 1.5f; mt->qthr[z] = 2.0f; }      // (fract <= 2 always; the group thresholds come out negative: no group is skipped)
-    // zero threshold of a group: qthr_z < fl(a * qmul_z + bias_z) < 1 (i.e. floor = 0, not flagged) for every |a| below t;
+        for (int z = 0; z < 64; ++z) { mt->bias[z] = 1.5f; mt->qadd[z] = 1.5f; mt->qthr[z] = 2.0f; }      // (fract <= 2 always; the group thresholds come out negative: no group is skipped)
+    // zero threshold of a group: qthr_z < fl(a * qmul_z + qadd_z) < 1 (i.e. floor = 0, not flagged) for every |a| below t;
     // the 2^-18 relative margin covers the single rounding of the kernel's fma
     for (int g = 0; g < 4; ++g)
         for (int h = 0; h < 2; ++h) {
             double t = 1.0e30;
             for (int j = 0; j < 8; ++j) {
                 const int z = 16 * g + 8 * h + j;
-                const double up = 1.0 - (double)mt->bias[z], dn = (double)mt->bias[z] - (double)mt->qthr[z];
+                const double up = 1.0 - (double)mt->qadd[z], dn = (double)mt->qadd[z] - (double)mt->qthr[z];
                 t = std::fmin(t, std::fmin(up, dn) / (double)mt->qmul[z]);
             }
             float fmax = 0.0f;

@@ -80,6 +80,7 @@ def _load() -> C.CDLL:
         "jpegamd_segment_meta_words": (i32, []),
         "jpegamd_debug_mfma_consts": (i32, [i32, vp, vp, vp, vp]),
         "jpegamd_debug_group_thresholds": (i32, [i32, vp, vp]),
+        "jpegamd_debug_mfma_offsets": (i32, [i32, vp, vp, vp, vp]),
         "jpegamd_debug_cos_lut": (i32, [vp]),
         "JpegCompression_Init": (i32, []),
         "JpegCompression_DeInit": (i32, []),
@@ -98,7 +99,7 @@ def _load() -> C.CDLL:
         "jpegamd_finalize_async": (i32, [vp, C.POINTER(Image), vp, u64, vp, i32, vp]),
     }
     for name, (res, args) in sig.items():
-        if name in ("jpegamd_encoder_set_pipeline", "jpegamd_gather_streams") and os.environ.get("JPEGAMD_LIB") and not hasattr(lib, name):
+        if name in ("jpegamd_encoder_set_pipeline", "jpegamd_gather_streams", "jpegamd_debug_mfma_offsets") and os.environ.get("JPEGAMD_LIB") and not hasattr(lib, name):
             continue                                              # (A/B tooling: a variant build of an older round)
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
@@ -108,7 +109,7 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTED = ("jpegamd_encoder_create jpegamd_encoder_destroy jpegamd_max_jfif_bytes jpegamd_encode_async jpegamd_encode_batch_async "
             "jpegamd_encoder_finish jpegamd_encoder_set_pipeline jpegamd_encoder_set_profiling jpegamd_encoder_profile jpegamd_debug_stages jpegamd_debug_dct_exact "
-            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_table jpegamd_segment_meta_words jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
+            "jpegamd_synth_bmp jpegamd_version jpegamd_debug_quant_table jpegamd_segment_meta_words jpegamd_debug_mfma_consts jpegamd_debug_group_thresholds jpegamd_debug_mfma_offsets jpegamd_debug_cos_lut JpegCompression_Init JpegCompression_DeInit JpegCompression_Reserve "
             "convertToJpeg JpegCompression_RemoteServiceHandler loadBMPImage freeBMPImage saveJPEGGrayscale "
             "jpegamd_encode_bmp_memory jpegamd_parse_bmp jpegamd_encode_files jpegamd_gather_streams "
             "jpegamd_encode_rows_async jpegamd_export_segments jpegamd_import_segments jpegamd_finalize_async").split()
@@ -128,12 +129,16 @@ SEG_META_WORDS = int(lib.jpegamd_segment_meta_words())      # metadata words per
 
 
 def mfma_consts(quality: int = 50):
-    """Constants of the matrix-pipe kernel: qmul/qthr/bias float32[64] by zigzag position, delta float64[64] by raster k."""
+    """Constants of the matrix-pipe kernel: qmul/qthr/bias/zoff/qadd float32[64] by zigzag position, delta float64[64] by raster k,
+    dc_off and scale (accumulator units)."""
     import numpy as np
     qmul, qthr = np.zeros(64, np.float32), np.zeros(64, np.float32)
     bias, delta = np.zeros(64, np.float32), np.zeros(64, np.float64)
     lib.jpegamd_debug_mfma_consts(quality, qmul.ctypes.data, qthr.ctypes.data, bias.ctypes.data, delta.ctypes.data)
-    return dict(qmul=qmul, qthr=qthr, bias=bias, delta=delta)
+    zoff, qadd = np.zeros(64, np.float32), np.zeros(64, np.float32)
+    dc_off, scale = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    lib.jpegamd_debug_mfma_offsets(quality, zoff.ctypes.data, qadd.ctypes.data, dc_off.ctypes.data, scale.ctypes.data)
+    return dict(qmul=qmul, qthr=qthr, bias=bias, delta=delta, zoff=zoff, qadd=qadd, dc_off=float(dc_off[0]), scale=float(scale[0]))
 
 
 def group_thresholds(quality: int = 50, with_lo_bound: bool = False):

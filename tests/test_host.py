@@ -123,8 +123,13 @@ def test_mfma_constants_are_on_the_safe_side(jpegamd, oracle):
             assert np.float64(c["qthr"][z]) <= 2.01 * c["delta"][k] + 4e-7    # no wider than needed (one bias for all positions was 2.3 x as wide on average)
             u, v = divmod(k, 8)
             kk = np.float32(np.float32(np.float32(0.25) * (np.float32(0.707107) if u == 0 else np.float32(1))) * (np.float32(0.707107) if v == 0 else np.float32(1)))
-            assert abs(float(c["qmul"][z]) * 2048.0 - float(kk) / float(table[k])) <= 1e-7 * float(kk)     # kMfmaScale = 2^11
+            assert abs(float(c["qmul"][z]) * c["scale"] - float(kk) / float(table[k])) <= 1e-7 * float(kk)     # the accumulator holds kMfmaScale x LUT sum
             assert float(c["qthr"][z]) < 0.01                                # (2.0 would mean: the integer split failed, everything is flagged)
+            # the uncentred operand's constant: five positions only, inside the band, and folded into what the fma adds
+            assert (c["zoff"][z] != 0) == (z in (6, 9, 21, 24, 27)), z
+            assert abs(float(c["zoff"][z])) <= 0.1 * c["delta"][k] and c["delta"][k] >= abs(float(c["zoff"][z])) * 1.0
+            assert np.float32(c["qadd"][z]) == np.float32(np.float64(np.float32(c["bias"][z])) + np.float64(np.float32(c["zoff"][z])))
+        assert c["scale"] == 2.0 ** -13 and c["dc_off"] == 1.0             # B operand = Y 2^-24, A terms = 2048 K: the DC row's surplus 64 x 128 is 1.0
         assert 1e-5 < c["delta"][1:].max() < 5e-3
 
 
@@ -134,7 +139,8 @@ def test_dc_closed_form(jpegamd):
       (a) the reference's DC value -- fl(scale * S) with scale = fl(fl(0.25 * 0.707107) * 0.707107) (dct.c:87-93), a correctly
           rounded float32 division by q and roundf (quantization.c:34-36) -- equals sign(S) * floor((|S| + 4 q) / (8 q)) for EVERY
           sum of 64 values in [-128, 127] and EVERY q in 1 .. 255 (the scale lies above 1/8: all ties go away from zero);
-      (b) the kernel's own evaluation, one float32 fma of 2048 |S| with the stored multiplier and bias of zigzag 0, then floor,
+      (b) the kernel's own evaluation, one float32 fma of kMfmaScale |S| (what is left of the DC row's accumulator once the
+          uncentred operand's surplus, dc_off, is taken off: exact) with the stored multiplier and bias of zigzag 0, then floor,
           gives that value for every S at every quality 1 .. 100, with a margin far above a float32 step."""
     f32, f64 = np.float32, np.float64
     S = np.arange(-128 * 64, 127 * 64 + 1, dtype=np.int64)
@@ -146,7 +152,10 @@ def test_dc_closed_form(jpegamd):
     for quality in range(1, 101):
         c = jpegamd.mfma_consts(quality)
         q0 = int(jpegamd.quant_table(quality)[0])
-        zc64 = np.abs(S).astype(f64) * 2048.0 * f64(c["qmul"][0]) + f64(f32(c["bias"][0]))  # 24 x 24 bits: the product is exact in float64
+        assert c["qadd"][0] == c["bias"][0]
+        acc = (f32(c["scale"]) * (S + 8192).astype(f32)).astype(f32)                         # the DC row: kMfmaScale x the sum of 64 values in 0 .. 255 (exact)
+        assert np.array_equal((acc - f32(c["dc_off"])).astype(f64), S.astype(f64) * c["scale"])       # ... minus the surplus: exact
+        zc64 = np.abs(S).astype(f64) * c["scale"] * f64(c["qmul"][0]) + f64(f32(c["bias"][0]))  # 24 x 24 bits: the product is exact in float64
         n = np.floor(zc64.astype(f32)).astype(np.int64) * np.sign(S)
         assert np.array_equal(n, np.sign(S) * ((np.abs(S) + 4 * q0) // (8 * q0))), quality
         margin = np.abs(zc64 - np.rint(zc64)).min()                                          # the ties sit delta above an integer
@@ -163,24 +172,25 @@ def test_group_zero_thresholds_are_safe(jpegamd):
     zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
     lut = jpegamd.cos_lut().astype(np.float64)
-    lo_true = np.zeros((4, 2))                                     # |lo-chain output| <= 128 x sum |lo term|, per group and lane half
+    scale = jpegamd.mfma_consts(50)["scale"]
+    lo_true = np.zeros((4, 2))                                     # |lo-chain output| <= 128 x (sum |lo term| + |sum lo term|) (the operand is Y = p + 128), per group and lane half
     for z in range(64):
         u, v = divmod(zz[z], 8)
         K = np.outer(lut[:, u], lut[:, v]).reshape(64)
-        lo = np.rint((K - np.rint(K * 2048.0) / 2048.0) * 4194304.0) / 2048.0
-        lo_true[z >> 4, (z >> 3) & 1] = max(lo_true[z >> 4, (z >> 3) & 1], 128.0 * np.abs(lo).sum())
+        lo = np.rint((K - np.rint(K * 2048.0) / 2048.0) * 4194304.0)            # in units of 2^-22
+        lo_true[z >> 4, (z >> 3) & 1] = max(lo_true[z >> 4, (z >> 3) & 1], scale * 128.0 * (np.abs(lo).sum() + abs(lo.sum())) / 4194304.0)
     for q in (50, 10, 90, 1, 100):
         c = jpegamd.mfma_consts(q)
         thr, lob = jpegamd.group_thresholds(q, with_lo_bound=True)
         assert (lob.astype(np.float64) >= lo_true).all()
-        assert (thr > 0).all() and (lob > 0).all() and (lob <= 4096.0 * 1.001).all()      # 64 terms x |p| <= 128 x |lo| <= 1024 / 2048
+        assert (thr > 0).all() and (lob > 0).all() and (lob <= scale * 2.0 * 1.001).all()    # 64 terms x |p| <= 128 x |lo| <= 1024 units of 2^-22
         for g in range(4):
             for h in range(2):
                 t = f32((np.float64(thr[g, h]) + np.float64(lob[g, h])) * (1.0 + 2.0 ** -23))
                 for j in range(8):
                     z = 16 * g + 8 * h + j
                     for a in (t, -t, np.nextafter(t, f32(0)), -np.nextafter(t, f32(0))):
-                        zc = f32(np.float64(a) * np.float64(c["qmul"][z]) + np.float64(f32(c["bias"][z])))      # one rounding, like v_fma_f32
+                        zc = f32(np.float64(a) * np.float64(c["qmul"][z]) + np.float64(f32(c["qadd"][z])))      # one rounding, like v_fma_f32
                         assert f32(c["qthr"][z]) < zc < f32(1.0), (q, g, h, j, float(a), float(zc))
         if 10 <= q <= 90:
             assert thr[0].min() <= thr[3].max()                     # coarser quantisation higher up: larger zero zone (Q=1 / 100: every step is 255 / 1)
@@ -188,7 +198,8 @@ def test_group_zero_thresholds_are_safe(jpegamd):
 
 def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
     """The matrix-pipe path on the CPU: the LUT-product matrix as two integer-valued binary16 terms (hi = round(2^11 K),
-    lo = round(2^22 (K - hi 2^-11)) stored as lo 2^-11), one accumulator chain per term, float32 accumulation in three
+    lo = round(2^22 (K - hi 2^-11)) stored as lo 2^-11), the B operand the UNCENTRED luma Y = p + 128 as the binary16 subnormal
+    Y 2^-24, one accumulator chain per term, float32 accumulation in three
     different orders (the hardware's order inside an MFMA is not specified).  Every chain must come out EXACT in every
     order; then one float32 add joins them, followed by the kernel's fma and flag test.  A coefficient the guard does NOT
     flag must equal the reference's quantised value, and the observed |z_fast - z_ref| must stay below delta (random, flat,
@@ -197,7 +208,7 @@ def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
     zz = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
           35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
     lut = jpegamd.cos_lut()                                        # COS_LUT[x][u] as compiled into the kernels
-    SCALE = 2048.0                                                 # kMfmaScale
+    SCALE = 2048.0                                                 # the A terms are 2048 K (hi) and 2048 K-residual (lo 2^-11)
 
     K = np.zeros((64, 64))
     for k in range(64):
@@ -215,10 +226,13 @@ def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
     P = np.array(blocks, dtype=np.int64)
     ref = oracle.dct_blocks(P.reshape(-1, 8, 8).astype(np.int8)).reshape(-1, 64)
 
+    Y = (P + 128).astype(f64) * 2.0 ** -24                        # the B operand: 0 .. 255 as binary16 subnormals
+    assert np.array_equal(((P + 128).astype(np.uint16).view(np.float16)).astype(f64), Y)          # the integer IS the bit pattern
+
     def chain(t, order):
         acc = np.zeros((len(P), 64), f32)
-        prod = (t[None, :, :] * P[:, None, :].astype(f64)).astype(f32)              # exact in float32: 11 x 8 significant bits
-        assert np.array_equal(prod.astype(f64), t[None, :, :] * P[:, None, :].astype(f64))
+        prod = (t[None, :, :] * Y[:, None, :]).astype(f32)                          # exact in float32: 12 x 8 significant bits
+        assert np.array_equal(prod.astype(f64), t[None, :, :] * Y[:, None, :])
         for s in range(4):
             idx = list(range(16 * s, 16 * s + 16))
             if order == "reverse":
@@ -233,7 +247,7 @@ def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
                     acc = (acc + prod[:, :, i]).astype(f32)
         return acc
 
-    exact = [(P[:, None, :].astype(f64) * t[None, :, :]).sum(axis=2) for t in terms]
+    exact = [(Y[:, None, :] * t[None, :, :]).sum(axis=2) for t in terms]
     for q in (50, 90):
         c = jpegamd.mfma_consts(q)
         table = oracle.quant_table(q).astype(f32)
@@ -242,16 +256,22 @@ def test_mfma_guard_band_holds_on_float32_emulation(jpegamd, oracle):
             for got, want in zip(chains, exact):
                 assert np.array_equal(got.astype(f64), want), order                       # exact, whatever the order
             acc = (chains[1] + chains[0]).astype(f32)                                     # the kernel's one add
+            acc[:, 0] = (acc[:, 0] - f32(c["dc_off"])).astype(f32)                        # the DC row: the surplus of the uncentred sum (exact)
+            assert np.array_equal(acc[:, 0].astype(f64), P.sum(axis=1).astype(f64) * c["scale"])
             unflagged = 0
             for z in range(64):
                 k = zz[z]
-                zc = (acc[:, k].astype(f64) * f64(c["qmul"][z]) + f64(f32(c["bias"][z]))).astype(f32)      # v_fma_f32: one rounding
+                zc = (acc[:, k].astype(f64) * f64(c["qmul"][z]) + f64(f32(c["qadd"][z]))).astype(f32)      # v_fma_f32: one rounding
                 n = np.floor(zc).astype(np.int64)
+                # the value the kernel keeps for an AC site: round-to-nearest-even of acc x qmul (the magic-number fma), WITHOUT the row's constant
+                n_rne = np.rint((acc[:, k].astype(f64) * f64(c["qmul"][z]))).astype(np.int64)
                 flagged = (zc - np.floor(zc)) <= f32(c["qthr"][z])
                 want = np.array([int(np.float32(np.round(np.float32(r) / table[k]))) if abs(np.float32(r) / table[k]) % 1 != 0.5
                                  else int(np.sign(r) * np.ceil(abs(np.float32(r) / table[k]))) for r in ref[:, k]], np.int64)   # roundf: half away
                 assert np.array_equal(n[~flagged], want[~flagged]), (q, order, z)
-                z_fast = acc[:, k].astype(f64) * f64(c["qmul"][z])
+                if z:
+                    assert np.array_equal(n_rne[~flagged], want[~flagged]), (q, order, z)
+                z_fast = acc[:, k].astype(f64) * f64(c["qmul"][z]) + f64(f32(c["zoff"][z]))
                 z_ref = ref[:, k].astype(f64) / f64(table[k])
                 assert np.abs(z_fast - z_ref).max() <= c["delta"][k], (q, order, z)
                 unflagged += int((~flagged).sum())
