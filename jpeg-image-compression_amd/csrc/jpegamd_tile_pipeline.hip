@@ -457,12 +457,14 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         f32x16 acc[2][2];                      // [term][chain]
         // One chain = the four k-steps of one term (t) for one half of the matrix rows (H): four A fragments in one batch of
         // LDS reads, then four MFMAs back to back behind ONE wait.
-        const auto run_chain = [&](const int t, const int H) {
+        const auto load_afrag = [&](const int t, const int H, f16x8 (&afr)[4]) {
             const uint32_t *at = &s_afrag[((t * 2 + H) * 4 * 64 + lane) * 4];
-            f16x8 afr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) afr[i] = *reinterpret_cast<const f16x8 *>(&at[(i * 64) * 4]);
-            __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads ahead of the MFMAs (hipcc otherwise sinks each read next to its use)
+            __builtin_amdgcn_sched_barrier(0);     // keep the LDS reads where they are (hipcc otherwise sinks each read next to its use)
+        };
+        const auto mfma_chain = [&](const int t, const int H, const f16x8 (&afr)[4]) {
+            __builtin_amdgcn_sched_barrier(0);
             const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc[t][H] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0], bfrag[0], zero, 0, 0, 0);     // C = 0 as an inline constant: no accumulator clearing
 #pragma unroll
@@ -551,22 +553,21 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         // The transform in two halves of 32 matrix rows, the UPPER rows (zigzag 32..63: groups 2 and 3) first: one half's two
         // accumulator chains are 32 registers.  In photo-like content the upper groups are dead in two tiles of three: the test on their
         // hi sums decides whether the half's lo chain runs at all (4 of the 16 MFMAs; an MFMA costs the SIMD's vector side 10-20 cycles
-        // beside the other waves, profiles/r04_ubench_mfma_overlap.txt).  The lower half's B operands are re-read from the luma stash.
-        run_chain(1, 1);
+        // beside the other waves, profiles/r04_ubench_mfma_overlap.txt).  A chain's A fragments are read from LDS one chain AHEAD (their
+        // latency runs beside the matrix pipe and the zero tests: -1.5 % per launch of eight), and the B fragments stay in registers for
+        // both halves (re-reading them from the luma stash, as the five-waves-per-SIMD attempt needed, cost four more LDS reads).
+        f16x8 afrA[4], afrB[4];
+        load_afrag(1, 1, afrA);
+        load_afrag(1, 0, afrB);                      // (the lower half's hi terms: on their way while the upper half's chain runs and is tested)
+        mfma_chain(1, 1, afrA);
         gact[2] = group_alive(2);
         gact[3] = group_alive(3);
-        if (kTaps || (gact[2] | gact[3]) != 0) run_chain(0, 1);
+        if (kTaps || (gact[2] | gact[3]) != 0) { load_afrag(0, 1, afrA); mfma_chain(0, 1, afrA); }
         quantise_group(2);
         quantise_group(3);
-        {
-            uint32_t sl2;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl2));
-            const uint32_t *const sp1 = &s_pix[wave][(sl2 >> 5) * 132 + (sl2 & 31) * 4];
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) bfrag[s4] = *reinterpret_cast<const f16x8 *>(&sp1[2 * s4 * 132]);
-        }
-        run_chain(1, 0);
-        run_chain(0, 0);
+        load_afrag(0, 0, afrA);
+        mfma_chain(1, 0, afrB);
+        mfma_chain(0, 0, afrA);
         TSTAMP(3);   // MFMA (+ the upper half's quantiser)
         const uint32_t ticket_v = ticket();          // (requested here, collected behind the counts: at the top of the iteration or behind the luma
                                                      //  conversion measured 1.2 % slower -- a wave then sits longer on a reserved, unstarted tile at the end)
