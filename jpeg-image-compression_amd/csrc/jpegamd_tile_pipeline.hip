@@ -431,7 +431,8 @@ void k_tile_encode(const ImageDesc im, const TransformOutM out, const TileSched 
         {
         uint32_t sl;                           // (an opaque lane id: the stash addresses are not worth four registers across the whole loop)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(sl));
-        uint32_t *const sp0 = &s_pix[wave][(sl >> 5) * 132 + (sl & 31) * 4];
+        // word (sl >> 5) * 132 + (sl & 31) * 4, as bytes: 16 sl + 16 (sl >> 5) -- two shifts, an and, an add (the product with 132 compiled to a v_mul_lo_u32)
+        uint32_t *const sp0 = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(&s_pix[wave][0]) + ((sl << 4) + ((sl >> 1) & 16u)));
 #pragma unroll
         for (int s = 0; s < 4; ++s) *reinterpret_cast<f16x8 *>(&sp0[2 * s * 132]) = bfrag[s];     // (one address, four immediate offsets)
         }
