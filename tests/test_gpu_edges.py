@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import random
 
+import numpy as np
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -197,3 +199,57 @@ def test_c_level_gather_of_streams_over_rccl(jpegamd, oracle, dev):
         assert jpegamd.lib.jpegamd_gather_streams(None, 0, 1, 0, records.data_ptr(), slot_bytes, slots, C.addressof(sizes), recv.data_ptr(), stride, None) == -1
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+def _gray_bmp(y: np.ndarray) -> bytes:
+    """24-bit bottom-up BMP whose three channels all equal `y` (uint8 [H, W]): the luma weights sum to 256, so Y == y exactly."""
+    h, w = y.shape
+    stride = (3 * w + 3) & ~3
+    rows = np.zeros((h, stride), np.uint8)
+    rows[:, :3 * w] = np.repeat(y[::-1], 3, axis=1)
+    head = b"BM" + (54 + stride * h).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little")
+    info = (40).to_bytes(4, "little") + w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + bytes(24)
+    return head + info + rows.tobytes()
+
+
+@pytest.mark.gpu
+def test_extreme_blocks_through_the_subnormal_matrix_operand(jpegamd, oracle, dev):
+    """The transform's B operand is the uncentred luma 0 .. 255 as binary16 subnormals: its exactness rests on every
+    partial sum of a chain staying below 2^24 units whatever order the matrix pipe adds in.  The pictures that push the sums furthest --
+    for each of the 64 basis functions the block that is 255 where the function is positive and 0 elsewhere, its complement, all-white,
+    all-black, checkerboards, single bright / dark pixels -- go through the kernel at the finest, the default and a coarse quantiser
+    (Q=100: every step is 1, the largest coefficient magnitudes) and must come out byte-identical to the oracle; the stage taps pin
+    the quantised coefficients themselves."""
+    lut = jpegamd.cos_lut().astype(np.float64)
+    blocks = []
+    for k in range(64):
+        u, v = divmod(k, 8)
+        pos = np.outer(lut[:, u], lut[:, v]) > 0
+        blocks += [np.where(pos, 255, 0), np.where(pos, 0, 255), np.where(pos, 255, 1), np.where(pos, 128, 127)]
+    blocks += [np.full((8, 8), 255), np.zeros((8, 8), int), (np.indices((8, 8)).sum(0) % 2) * 255, (np.indices((8, 8))[0] % 2) * 255]
+    for p in ((0, 0), (7, 7), (3, 4)):
+        b = np.zeros((8, 8), int); b[p] = 255; blocks.append(b)
+        b = np.full((8, 8), 255); b[p] = 0; blocks.append(b)
+    rng = np.random.default_rng(4)
+    blocks += [rng.choice([0, 255], size=(8, 8)) for _ in range(58)]
+    nb = len(blocks)
+    per_row = 40                                                   # 320 pixels: a full tile and a ragged one per block row
+    rows = (nb + per_row - 1) // per_row
+    y = np.zeros((rows * 8, per_row * 8), np.uint8)
+    for i, b in enumerate(blocks):
+        y[(i // per_row) * 8:(i // per_row) * 8 + 8, (i % per_row) * 8:(i % per_row) * 8 + 8] = b
+    bmp = _gray_bmp(y)
+    enc = jpegamd.Encoder(y.shape[1], y.shape[0])
+    for q in (100, 50, 10):
+        got = _encode_batch(jpegamd, [bmp], q, dev)[0]
+        assert got == oracle.encode_bmp(bmp, q), q
+    st = oracle.stages(bmp)
+    img, off = jpegamd.parse_bmp(bmp)
+    px = torch.frombuffer(bytearray(bmp[off:off + img.row_stride * img.height]), dtype=torch.uint8).to(dev)
+    n = st["zigzag"].shape[0]
+    yt = torch.zeros(n * 64, dtype=torch.int8, device=dev)
+    zz = torch.zeros(n * 64, dtype=torch.int16, device=dev)
+    mask = torch.zeros(n, dtype=torch.int64, device=dev)
+    d = jpegamd.Encoder.image(px.data_ptr(), img.width, img.height, img.row_stride, bool(img.bottom_up))
+    enc.debug_stages(d, yt.data_ptr(), zz.data_ptr(), mask.data_ptr())
+    assert np.array_equal(zz.cpu().numpy().reshape(n, 64), st["zigzag"])
