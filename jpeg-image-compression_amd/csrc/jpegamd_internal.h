@@ -74,7 +74,7 @@ constexpr int kTileOverCap = ((kTileBlocks * kMaxBlockBits + 31) / 32 + 2 + 63) 
 // (A dense array for the segments' strings as well was measured: k_finalize 38 -> 51 us per launch of eight pictures.)
 
 struct MfmaTables {
-    uint32_t afrag[kAFragWords];   // kMfmaScale * LUT-product matrix as two integer-valued binary16 terms (lo 2^-11, hi), MFMA A-operand order
+    uint32_t afrag[kAFragWords];   // 2048 x the LUT-product matrix as two integer-valued binary16 terms (lo 2^-11, hi), MFMA A-operand order (the B operand brings 2^-24)
     float qmul[64];                // by zigzag position z: M_z = K / (q * kMfmaScale)  (the MFMA output is kMfmaScale * LUT sum)
     float qthr[64];                // flag threshold 2 (bias_z - 0.5), exactly (the kernel derives it as fma(2, bias_z, -1))
     float qstep[64];               // (float) q, by zigzag position
